@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: generate the committed golden vectors under tests/golden/.
+
+Runs ONLY in the build container (needs /root/reference and oracle/_ref/ref_harness, built by
+`make -C oracle ref`).  For each fixture it (1) writes a small synthetic STRUCTURE-format input with a
+fixed Python `random` seed, (2) runs the reference-linked harness (oracle/ref_harness.c) on it, which
+dumps inputs and the reference's outputs at full precision.  Fixtures are data only (inputs + expected
+outputs); no reference source is copied.  Re-run: `python oracle/make_fixtures.py`.
+"""
+import os, random, shutil, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+
+
+def write_stru(path, I, L, K, ploidy, nalleles, seed, missing=0.0, allele_codes=None):
+    """nalleles: list of per-locus allele counts. Individuals are admixed 0.8/0.2 around locale i%K."""
+    rnd = random.Random(seed)
+    P = []
+    for l in range(L):
+        M = nalleles[l]
+        rows = []
+        for k in range(K):
+            g = [rnd.gammavariate(0.5, 1.0) + 1e-3 for _ in range(M)]
+            s = sum(g)
+            rows.append([x / s for x in g])
+        P.append(rows)
+    with open(path, "w") as f:
+        f.write(" ".join("loc%d" % (l + 1) for l in range(L)) + "\n")
+        for i in range(I):
+            pop = i % K
+            q = [0.2 / (K - 1) if K > 1 else 1.0] * K
+            q[pop] = 0.8 if K > 1 else 1.0
+            for a in range(ploidy):
+                row = []
+                for l in range(L):
+                    k = rnd.choices(range(K), q)[0]
+                    m = rnd.choices(range(nalleles[l]), P[l][k])[0]
+                    code = allele_codes[l][m] if allele_codes else m + 1
+                    if missing and rnd.random() < missing:
+                        code = -9
+                    row.append(str(code))
+                f.write("ind%d pop%d " % (i, pop) + " ".join(row) + "\n")
+
+
+def write_c1(path):
+    """SURVEY.md App. D generator for the config-1 plumbing case (100 x 500 biallelic, K=3)."""
+    random.seed(42)
+    I, L, K = 100, 500, 3
+    P = [[random.betavariate(0.5, 0.5) for _ in range(L)] for _ in range(K)]
+    with open(path, "w") as f:
+        f.write(" ".join("loc%d" % (l + 1) for l in range(L)) + "\n")
+        for i in range(I):
+            pop = i % K
+            q = [0.1] * K
+            q[pop] = 0.8
+            for a in range(2):
+                row = []
+                for l in range(L):
+                    k = random.choices(range(K), q)[0]
+                    row.append("1" if random.random() < P[k][l] else "2")
+                f.write("ind%d pop%d " % (i, pop) + " ".join(row) + "\n")
+
+
+def run(name, stru, n_em, snaps, n_cycles, args, keep_ilm=True):
+    out = os.path.join(GOLD, name)
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    cmd = [HARNESS, out, str(n_em), snaps, str(n_cycles), "--", "-f", stru] + args
+    print(" ".join(cmd))
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, cwd=out)
+    with open(os.path.join(out, "ARGS.txt"), "w") as f:
+        f.write(" ".join(["-f", os.path.basename(stru)] + args) + "\n")
+    if not keep_ilm:
+        os.remove(os.path.join(out, "ilm.i32"))
+    for fn in os.listdir(out):      # stray files the reference may write into cwd
+        if fn.endswith(".txt") and fn not in ("ARGS.txt",):
+            os.remove(os.path.join(out, fn))
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        sys.exit("build oracle/_ref/ref_harness first: make -C oracle ref")
+    data = os.path.join(GOLD, "data")
+    os.makedirs(data, exist_ok=True)
+
+    c1 = os.path.join(data, "c1_tiny.stru")
+    write_c1(c1)
+    rnd = random.Random(99)
+    multi = os.path.join(data, "multi.stru")
+    nal = [rnd.choice([2, 3, 4, 5]) for _ in range(60)]
+    codes = [sorted(rnd.sample(range(100, 200), nal[l])) for l in range(60)]   # non-contiguous allele codes
+    write_stru(multi, 40, 60, 4, 2, nal, seed=1, allele_codes=codes)
+    tetra = os.path.join(data, "tetra.stru")
+    write_stru(tetra, 30, 50, 3, 4, [rnd.choice([2, 3, 4]) for _ in range(50)], seed=2)
+    miss = os.path.join(data, "missing.stru")
+    write_stru(miss, 50, 80, 3, 2, [rnd.choice([2, 2, 3]) for _ in range(80)], seed=3, missing=0.03)
+
+    run("c1_admix_k3", c1, 100, "1,2,3,10,100", 5, ["-a", "-k", "3", "-r", "1234567", "-s", "3"], keep_ilm=False)
+    run("multi_admix_k4", multi, 30, "1,2,3,10,30", 3, ["-a", "-k", "4", "-r", "7", "-s", "3"])
+    run("multi_admix_k4_s1", multi, 3, "1,3", 3, ["-a", "-k", "4", "-r", "7", "-s", "1"])
+    run("multi_admix_k4_s2", multi, 3, "1,3", 3, ["-a", "-k", "4", "-r", "7", "-s", "2"])
+    run("multi_admix_k3_qn1", multi, 3, "1,3", 3, ["-a", "-k", "3", "-r", "7", "-s", "4"])
+    run("multi_admix_k3_qn2", multi, 3, "1,3", 3, ["-a", "-k", "3", "-r", "7", "-s", "5"])
+    run("multi_admix_k3_qn3", multi, 3, "1,3", 3, ["-a", "-k", "3", "-r", "7", "-s", "6"])
+    run("multi_admix_k1", multi, 2, "1,2", 0, ["-a", "-k", "1", "-r", "7"])
+    run("tetra_admix_k3", tetra, 20, "1,2,3,20", 3, ["-p", "4", "-a", "-k", "3", "-r", "11", "-s", "3"])
+    run("missing_admix_k3", miss, 20, "1,2,3,20", 3, ["-a", "-k", "3", "-r", "5", "-s", "3"])
+    run("multi_mix_k3", multi, 10, "1,2,3,10", 3, ["-k", "3", "-r", "5", "-s", "3"])
+    run("multi_admix_c_k3", multi, 10, "1,2,3,10", 3, ["-a", "-c", "-k", "3", "-r", "5", "-s", "3"])
+    run("missing_mix_k2", miss, 5, "1,5", 0, ["-k", "2", "-r", "5"])
+
+
+if __name__ == "__main__":
+    main()
