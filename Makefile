@@ -1,0 +1,39 @@
+# Top-level build: HIP library (gfx950), host C library, oracle (test infrastructure).
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Imulticlust_amd/csrc -Wall -Wno-unused-function
+CFLAGS   = -std=c11 -O2 -fPIC -Wall -Wextra -Iinclude
+
+OBJ  = build/obj
+LIB  = multiclust_amd/lib
+KS   = 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16
+KOBJ = $(foreach k,$(KS),$(OBJ)/mchip_k$(k).o)
+
+all: $(LIB)/libmulticlust_hip.so $(LIB)/libmulticlust_host.so oracle
+
+$(OBJ)/mchip_k%.o: multiclust_amd/csrc/mchip_kernels_k.hip multiclust_amd/csrc/mchip_internal.h include/multiclust_hip.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -DMCHIP_K=$* -c $< -o $@
+
+$(OBJ)/mchip.o: multiclust_amd/csrc/mchip.hip multiclust_amd/csrc/mchip_internal.h include/multiclust_hip.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB)/libmulticlust_hip.so: $(OBJ)/mchip.o $(KOBJ)
+	@mkdir -p $(LIB)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+HOST_SRC = $(wildcard multiclust_amd/host/*.c)
+$(LIB)/libmulticlust_host.so: $(HOST_SRC) $(wildcard multiclust_amd/host/*.h) include/multiclust_hip.h $(LIB)/libmulticlust_hip.so
+	@mkdir -p $(LIB)
+	$(CC) $(CFLAGS) -Imulticlust_amd/host -shared -o $@ $(HOST_SRC) -L$(LIB) -lmulticlust_hip -Wl,-rpath,'$$ORIGIN' -lm
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -rf build $(LIB)/*.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,142 @@
+/*
+ * multiclust_hip.h -- C-ABI of the MI355X-native EM hot path of MULTICLUST.
+ *
+ * Drop-in boundary.  The reference has no FFI: the seam is the set of C functions
+ * its driver/init/writer layers call on the EM layer, all taking (options*, data*, model*)
+ * (reference multiclust.h:371-388).  Each entry point below names the reference function(s) it replaces
+ * (file:line under the reference checkout).  Conventions:
+ *   - extern "C", plain pointers and sizes; no pointer into device memory crosses this boundary;
+ *   - every function returns int, 0 = MCHIP_OK (reference: NO_ERROR, message.h:21); nothing here calls
+ *     exit() -- the host keeps the reference's exit(0)-on-NaN/decrease semantics (em_alg.c:106-120);
+ *   - an opaque context owns one HIP stream and all device buffers for (device, data set, K); contexts
+ *     share nothing, so independent initialisations / bootstrap replicates can run one per stream;
+ *   - parameters cross the boundary in the reference's own flat order:
+ *       P[k][l][m]  -> double[K*T],  T = sum_l uniquealleles[l], index k*T + T_off[l] + m  (vpklm[slot][k][l][m])
+ *       Q[i][k]     -> double[I*K]   (vetaik[slot][i][k]);  double[K] when eta is constrained / mixture (vetak[slot])
+ *   - slots 0..2 are the reference's triple buffers vpklm[3]/vetaik[3] (multiclust.h:266-271).
+ */
+#ifndef MULTICLUST_HIP_H
+#define MULTICLUST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCHIP_ABI_VERSION 1
+#define MCHIP_MISSING 0xFF	/* genotype byte for a missing allele copy (reference MISSING = -9, multiclust.h:140) */
+#define MCHIP_MAX_K 16		/* clusters supported by the specialised kernels this round */
+#define MCHIP_MAX_SECANTS 3	/* options::q <= 3 without LAPACK (multiclust.c:847-851) */
+
+enum mchip_status {
+	MCHIP_OK = 0,
+	MCHIP_ERR_INVALID = 1,		/* bad argument / shape */
+	MCHIP_ERR_NO_DEVICE = 2,	/* no HIP device: the product path fails loudly, there is no CPU fallback */
+	MCHIP_ERR_HIP = 3,		/* a HIP runtime call failed; see mchip_last_error() */
+	MCHIP_ERR_ALLOC = 4,
+	MCHIP_ERR_STATE = 5,		/* called out of order (no genotypes / no model yet) */
+	MCHIP_ERR_UNSUPPORTED = 6
+};
+
+typedef struct mchip_context mchip_context;
+
+int mchip_abi_version(void);
+int mchip_device_count(int *count);
+/* One context per (device, stream).  Replaces make_model/allocate_model_for_k ownership (multiclust.c:1087,1181). */
+int mchip_create(mchip_context **ctx, int device);
+int mchip_destroy(mchip_context *ctx);
+const char *mchip_last_error(const mchip_context *ctx);
+int mchip_synchronize(mchip_context *ctx);
+
+/*
+ * Upload one data set.  Replaces dat->IL / dat->L_alleles / dat->ILM as built by read_file.c:443-663:
+ * geno[i][l][a] (I*L*ploidy bytes) is the index of allele copy a of individual i at locus l in that
+ * locus's ascending allele list (the reference's own index form dat->ila, read_file.c:374-401), or
+ * MCHIP_MISSING.  uniquealleles[l] = M_l includes the phantom trailing slot the reference creates for
+ * loci with missing data (read_file.c:527-533); indices must be < M_l.  Called again per bootstrap
+ * replicate (bootstrap.c:35-41 swaps dat->ILM).
+ */
+int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy,
+			const int32_t *uniquealleles, const uint8_t *geno);
+
+/*
+ * Allocate parameter ring, secant buffers and workspaces for K.  Replaces allocate_model_for_k
+ * (multiclust.c:1181-1265) and free_model_data (1288).  admixture/eta_constrained/do_projection are
+ * options::admixture / eta_constrained / do_projection; the lower bounds are options::eta_lower_bound and
+ * p_lower_bound after synchronize() (multiclust.c:812-815); n_secants is options::q.
+ */
+int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constrained, int do_projection,
+		    double eta_lower_bound, double p_lower_bound, int n_secants);
+
+/* Parameter slots: mod->vpklm[slot], mod->vetaik[slot] / mod->vetak[slot]. */
+int mchip_set_p(mchip_context *ctx, int slot, const double *p);
+int mchip_get_p(mchip_context *ctx, int slot, double *p);
+int mchip_set_q(mchip_context *ctx, int slot, const double *q);
+int mchip_get_q(mchip_context *ctx, int slot, double *q);
+int mchip_q_length(const mchip_context *ctx, int *n);	/* I*K or K */
+int mchip_p_length(const mchip_context *ctx, int *n);	/* K*T */
+
+/*
+ * One EM iteration: E step on slot `from`, M step into slot `to` (may be equal: in place, as the
+ * unaccelerated reference does).  Replaces e_step_admixture_orig + m_step_admixture_orig
+ * (em_alg.c:291-486, 592-754) or e_step_mixture + m_step_mixture (763-1011) as sequenced by em_step
+ * (195-207); d_iklm is never materialised.  *loglik = log likelihood of the `from` parameters (what the
+ * reference's E step returns).  loglik may be NULL: the step is then only enqueued (no host sync);
+ * fetch the value later with mchip_last_loglik().
+ */
+int mchip_em_step(mchip_context *ctx, int from, int to, double *loglik);
+int mchip_last_loglik(mchip_context *ctx, double *loglik);
+/* E step only (em_e_step's trailing E step, em_alg.c:226,230): refreshes the expected counts, returns logL. */
+int mchip_e_step(mchip_context *ctx, int slot, double *loglik);
+/* log_likelihood(): logL_admixture / logL_mixture (log_likelihood.c:96-147, 157-232). */
+int mchip_loglik(mchip_context *ctx, int slot, double *loglik);
+
+/*
+ * First M step from a hard allele partition: random_initialize_admixture (rnd_init.c:349-357) =
+ * random_allele_partition (456-482) + m_step_admixture.  assign[i][l][a] in [0,K) is the cluster drawn for
+ * allele copy a (the host draws it with the libc-compatible stream); d_iklm = 1 (not += 1) per matching copy.
+ */
+int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to);
+
+/*
+ * What the writers read from diklm / vik (write_file.c:359-381,446-459,531-542,593-598):
+ * admixture: sik[i][k] = sum_{l,m} d_iklm of the last E step executed; mixture: vik[i][k].
+ */
+int mchip_get_expected_counts(mchip_context *ctx, double *sik);
+
+/* ---- acceleration (accel_em.c, em_alg.c:1072-1211) ---- */
+/* u (which=0) or v (which=1) secant j := x[to] - x[from], for p and eta (em_alg.c:1104-1161). */
+int mchip_secant(mchip_context *ctx, int which, int j, int to, int from);
+/* utu, utvu, vutvu of secant pair j, eta terms then p terms (accel_em.c:143-184). out[3]. */
+int mchip_step_dots(mchip_context *ctx, int j, double *out3);
+/* u_{j1}.u_{j2} and u_{j1}.v_{j2} (quasi-Newton secant matrix, accel_em.c:291-310). out[2]. */
+int mchip_secant_dots(mchip_context *ctx, int j1, int j2, double *out2);
+/*
+ * accelerated_update (accel_em.c:444-541): x[to] = x[base] - 2 s u_j + s^2 (v_j - u_j)  (qn_form = 0, SQUAREM)
+ *                                       or x[base] + u_j + s v_j                         (qn_form = 1, QN q=1),
+ * then simplex projection of every (k,l) block and every individual when do_projection.
+ */
+int mchip_accel_update(mchip_context *ctx, int to, int base, int j, double s, int qn_form);
+/*
+ * qn_accelerated_update (accel_em.c:364-415): x[to] = x[base] + u_{u_index}; then for t = 0..n_terms-1, in
+ * order, x[to] += v_{v_index[t]} * coef_a[t] * coef_b[t]  (Ainv[j*q+n] and cutu[n]); then projection.
+ */
+int mchip_multisecant_update(mchip_context *ctx, int to, int base, int u_index, int n_terms,
+			     const int *v_index, const double *coef_a, const double *coef_b);
+
+/* ---- measurement hooks (bench.py): HIP events on the context's own stream ---- */
+int mchip_profile_begin(mchip_context *ctx);
+/* total_ms: begin..end on the stream.  kernel_ms[MCHIP_PROF_KINDS] / launches[MCHIP_PROF_KINDS]: summed
+ * durations and launch counts of the streaming passes over the genotype matrix, each launch bracketed
+ * by its own event pair: [0] column pass of an EM step (N-side sums + logL), [1] individual pass
+ * (S-side sums), [2] stand-alone log-likelihood pass. */
+#define MCHIP_PROF_KINDS 3
+int mchip_profile_end(mchip_context *ctx, double *total_ms, double *kernel_ms, int *launches);
+/* device properties the bench reports (name, CU count, memory) */
+int mchip_device_info(mchip_context *ctx, char *name, int name_len, int *compute_units, double *hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,920 @@
+/*
+ * mchip.hip -- context management, K-independent kernels and the C-ABI entry points of
+ * libmulticlust_hip.so (include/multiclust_hip.h).  gfx950 only; no CPU fallback: every entry point
+ * fails with MCHIP_ERR_NO_DEVICE / MCHIP_ERR_HIP when the GPU path cannot run.
+ */
+#include "mchip_internal.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ per-K tables */
+#define DECL_KT(n) const mchip_ktable *mchip_ktable_get_##n();
+DECL_KT(1) DECL_KT(2) DECL_KT(3) DECL_KT(4) DECL_KT(5) DECL_KT(6) DECL_KT(7) DECL_KT(8)
+DECL_KT(9) DECL_KT(10) DECL_KT(11) DECL_KT(12) DECL_KT(13) DECL_KT(14) DECL_KT(15) DECL_KT(16)
+
+const mchip_ktable *mchip_get_ktable(int K)
+{
+	typedef const mchip_ktable *(*getter)();
+	static const getter tabs[MCHIP_MAX_K + 1] = {
+		nullptr, mchip_ktable_get_1, mchip_ktable_get_2, mchip_ktable_get_3, mchip_ktable_get_4, mchip_ktable_get_5,
+		mchip_ktable_get_6, mchip_ktable_get_7, mchip_ktable_get_8, mchip_ktable_get_9, mchip_ktable_get_10,
+		mchip_ktable_get_11, mchip_ktable_get_12, mchip_ktable_get_13, mchip_ktable_get_14, mchip_ktable_get_15,
+		mchip_ktable_get_16,
+	};
+	return (K >= 1 && K <= MCHIP_MAX_K) ? tabs[K]() : nullptr;
+}
+
+/* ------------------------------------------------------------------ context */
+struct mchip_context {
+	int device;
+	hipStream_t stream;
+	char err[512];
+	int n_cu;
+	/* data set */
+	int I, L, ploidy, T, max_M;
+	int32_t *d_ua, *d_toff, *d_col_locus;
+	uint8_t *d_col_allele;
+	uint8_t *d_gtA, *d_gtS;
+	size_t geno_bytes_A, geno_bytes_S;
+	uint8_t *d_asA, *d_asS;		/* hard-partition scratch, allocated on first use */
+	/* model */
+	int K, admixture, constrained, do_projection, nsec, nq, qstride;
+	double eta_lb, p_lb;
+	const mchip_ktable *kt;
+	double *d_p[3], *d_q[3];
+	double *d_up[MCHIP_MAX_SECANTS], *d_vp[MCHIP_MAX_SECANTS], *d_uq[MCHIP_MAX_SECANTS], *d_vq[MCHIP_MAX_SECANTS];
+	double *d_sik;			/* [I][K] expected counts / vik */
+	double *d_stage;		/* K*T staging for the [K][T] <-> [T][K] transposes */
+	/* workspaces */
+	int ichunk, n_ichunks, lchunk, n_lchunks, n_llpart, flush_every;
+	double *d_Apart, *d_Spart, *d_llpart, *d_scalars;	/* d_scalars: [0]=logL, [1..3]=dots, [4..]=eta sums */
+	double *d_redpart;		/* block partials of the dot products / column sums */
+	uint8_t *d_flags;		/* michelot "fixed" flags for loci with more than 64 alleles */
+	double *h_pinned;		/* 64 doubles */
+	int have_ll;
+	/* profiling */
+	int profiling;
+	hipEvent_t ev_begin, ev_end;
+	std::vector<hipEvent_t> ev_pool;
+	std::vector<int> ev_kind;	/* kernel kind of pair p = events 2p, 2p+1 */
+	size_t ev_used;
+};
+
+static int fail(mchip_context *ctx, int code, const char *fmt, const char *detail)
+{
+	if (ctx) snprintf(ctx->err, sizeof ctx->err, fmt, detail ? detail : "");
+	return code;
+}
+
+#define HIPCHK(call)                                                                                  \
+	do {                                                                                          \
+		hipError_t e_ = (call);                                                               \
+		if (e_ != hipSuccess) {                                                               \
+			snprintf(ctx->err, sizeof ctx->err, "%s failed: %s (%s:%d)", #call,           \
+				 hipGetErrorString(e_), __FILE__, __LINE__);                          \
+			return MCHIP_ERR_HIP;                                                         \
+		}                                                                                     \
+	} while (0)
+
+template <typename Tp> static void dfree(Tp *&p)
+{
+	if (p) (void)hipFree(p);
+	p = nullptr;
+}
+
+/* ------------------------------------------------------------------ K-independent kernels */
+
+/* raw [I][L][pl] bytes -> gtA [ceil(I/8)][L][8][pl] and gtS [ceil(L/8)][I][8][pl]; pads with 0xFF;
+ * validates allele indices when ua != nullptr (limit = ua[l]) or against `limit` otherwise */
+__global__ void k_relayout(const uint8_t *__restrict__ raw, int I, int L, int pl, const int32_t *__restrict__ ua,
+			   int limit, uint8_t *gtA, uint8_t *gtS, size_t nA, size_t nS, int *bad)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx < nA) {
+		size_t r = idx;
+		const int a = (int)(r % pl); r /= pl;
+		const int j = (int)(r % 8); r /= 8;
+		const int l = (int)(r % L);
+		const size_t ib = r / L;
+		const size_t i = ib * 8 + j;
+		uint8_t v = 0xFF;
+		if (i < (size_t)I) {
+			v = raw[(i * L + l) * pl + a];
+			const int lim = ua ? ua[l] : limit;
+			if (v != 0xFF && (int)v >= lim) atomicOr(bad, 1);
+		}
+		gtA[idx] = v;
+	}
+	if (idx < nS) {
+		size_t r = idx;
+		const int a = (int)(r % pl); r /= pl;
+		const int j = (int)(r % 8); r /= 8;
+		const size_t i = r % I;
+		const size_t lb = r / I;
+		const size_t l = lb * 8 + j;
+		gtS[idx] = (l < (size_t)L) ? raw[(i * L + l) * pl + a] : (uint8_t)0xFF;
+	}
+}
+
+/* host order [K][T] <-> device order [T][K] */
+__global__ void k_transpose_kt_to_tk(const double *__restrict__ src, double *__restrict__ dst, int K, int T)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= (size_t)K * T) return;
+	const int k = (int)(idx % K);
+	const size_t c = idx / K;
+	dst[idx] = src[(size_t)k * T + c];
+}
+__global__ void k_transpose_tk_to_kt(const double *__restrict__ src, double *__restrict__ dst, int K, int T)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= (size_t)K * T) return;
+	const size_t c = idx % T;
+	const int k = (int)(idx / T);
+	dst[idx] = src[c * K + k];
+}
+
+/* deterministic sum of n doubles (fixed strided order, then a fixed tree): one block */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_sum(const double *__restrict__ in, int n, double *out)
+{
+	__shared__ double red[MCHIP_BLOCK];
+	double s = 0.0;
+	for (int x = threadIdx.x; x < n; x += MCHIP_BLOCK) s += in[x];
+	red[threadIdx.x] = s;
+	__syncthreads();
+	for (int w = MCHIP_BLOCK / 2; w > 0; w >>= 1) {
+		if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *out = red[0];
+}
+
+/* simplex.c:109-143 on a strided vector in memory; fixed-entry set kept in a 64-bit mask (len <= 64)
+ * or in byte flags (longer) */
+__device__ void michelot_strided(double *x, int stride, int len, double mn, uint8_t *flags)
+{
+	unsigned long long fixed = 0ull;
+	int n = len;
+	if (len > 64) for (int j = 0; j < len; j++) flags[(size_t)j * stride] = 0;
+	while (n) {
+		double csum = 0.0;
+		for (int j = 0; j < len; j++) csum += x[(size_t)j * stride];
+		const double shift = (csum - 1.0) / (double)n;
+		bool can_terminate = true;
+		for (int j = 0; j < len; j++) {
+			const bool is_fixed = (len > 64) ? (flags[(size_t)j * stride] != 0) : (((fixed >> j) & 1ull) != 0);
+			if (is_fixed) continue;
+			double v = x[(size_t)j * stride] - shift;
+			if (v < mn) {
+				v = mn;
+				if (len > 64) flags[(size_t)j * stride] = 1; else fixed |= 1ull << j;
+				n--;
+				can_terminate = false;
+			}
+			x[(size_t)j * stride] = v;
+		}
+		if (can_terminate) break;
+	}
+}
+
+/* P[to][l,.][k] = normalise(P[from] * sum_chunks Apart) then project (em_alg.c:706-752); thread = (l,k) */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_p(int L, int K, int T, const int32_t *__restrict__ toff,
+		int n_ichunks, const double *__restrict__ Apart, const double *Pfrom, double *Pto,
+		int weighted, double add_lb, int do_projection, double lb, uint8_t *flags)
+{
+	const size_t idx = (size_t)blockIdx.x * MCHIP_BLOCK + threadIdx.x;
+	if (idx >= (size_t)L * K) return;
+	const int k = (int)(idx % K);
+	const int l = (int)(idx / K);
+	const int c0 = toff[l], M = toff[l + 1] - c0;
+	double temp = 0.0;
+	for (int m = 0; m < M; m++) {
+		const size_t e = (size_t)(c0 + m) * K + k;
+		double s = 0.0;
+		for (int ch = 0; ch < n_ichunks; ch++) s += Apart[(size_t)ch * T * K + e];
+		if (weighted) s *= Pfrom[e];
+		s += add_lb;		/* mixture M step starts every sum at p_lower_bound (em_alg.c:972); 0 otherwise */
+		Pto[e] = s;
+		temp += s;
+	}
+	for (int m = 0; m < M; m++) Pto[(size_t)(c0 + m) * K + k] /= temp;
+	if (do_projection) michelot_strided(Pto + (size_t)c0 * K + k, K, M, lb, flags ? flags + (size_t)c0 * K + k : nullptr);
+}
+
+/* projection of every (l,k) block of a P slot (accelerated updates, accel_em.c:474-475) */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_project_p(int L, int K, const int32_t *__restrict__ toff, double *P,
+		double lb, uint8_t *flags)
+{
+	const size_t idx = (size_t)blockIdx.x * MCHIP_BLOCK + threadIdx.x;
+	if (idx >= (size_t)L * K) return;
+	const int k = (int)(idx % K);
+	const int l = (int)(idx / K);
+	const int c0 = toff[l], M = toff[l + 1] - c0;
+	michelot_strided(P + (size_t)c0 * K + k, K, M, lb, flags ? flags + (size_t)c0 * K + k : nullptr);
+}
+
+/* shared eta (eta_constrained): eta_k = sum_i S_ik / sum, project (em_alg.c:604-648): one block per k */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_column_sums(const double *__restrict__ sik, int I, int K, double *out)
+{
+	__shared__ double red[MCHIP_BLOCK];
+	const int k = blockIdx.x;
+	double s = 0.0;
+	for (int i = threadIdx.x; i < I; i += MCHIP_BLOCK) s += sik[(size_t)i * K + k];
+	red[threadIdx.x] = s;
+	__syncthreads();
+	for (int w = MCHIP_BLOCK / 2; w > 0; w >>= 1) {
+		if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) out[k] = red[0];
+}
+__global__ void k_normalize_row(const double *__restrict__ sums, int K, double *eta)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	double temp = 0.0;
+	for (int k = 0; k < K; k++) temp += sums[k];
+	for (int k = 0; k < K; k++) eta[k] = sums[k] / temp;
+}
+
+/* secant: out = x_to - x_from (em_alg.c:1104-1161) */
+__global__ void k_diff(const double *__restrict__ a, const double *__restrict__ b, double *out, size_t n)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx < n) out[idx] = a[idx] - b[idx];
+}
+
+/* three dot products of accel_em.c:143-184 (mode 0: utu, u(v-u), (v-u)^2) or the two of 291-310
+ * (mode 1: u1.u2, u1.v2) over one array pair; block partials, combined by k_reduce_sum */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_dots(const double *__restrict__ u, const double *__restrict__ v,
+		const double *__restrict__ u2, size_t n, int mode, double *part)
+{
+	__shared__ double red[3][MCHIP_BLOCK];
+	double s0 = 0, s1 = 0, s2 = 0;
+	for (size_t x = (size_t)blockIdx.x * MCHIP_BLOCK + threadIdx.x; x < n; x += (size_t)gridDim.x * MCHIP_BLOCK) {
+		if (mode == 0) {
+			const double uu = u[x], d = v[x] - uu;
+			s0 += uu * uu; s1 += uu * d; s2 += d * d;
+		} else {
+			const double uu = u[x];
+			s0 += uu * u2[x]; s1 += uu * v[x];
+		}
+	}
+	red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+	__syncthreads();
+	for (int w = MCHIP_BLOCK / 2; w > 0; w >>= 1) {
+		if ((int)threadIdx.x < w) {
+			red[0][threadIdx.x] += red[0][threadIdx.x + w];
+			red[1][threadIdx.x] += red[1][threadIdx.x + w];
+			red[2][threadIdx.x] += red[2][threadIdx.x + w];
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		part[blockIdx.x] = red[0][0];
+		part[gridDim.x + blockIdx.x] = red[1][0];
+		part[2 * gridDim.x + blockIdx.x] = red[2][0];
+	}
+}
+
+/* accel_em.c:444-541 element updates (projection follows in k_project_*) */
+__global__ void k_accel_update(const double *__restrict__ base, const double *__restrict__ u, const double *__restrict__ v,
+			       double *out, size_t n, double s, int qn_form)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= n) return;
+	if (qn_form) out[idx] = base[idx] + u[idx] + s * v[idx];
+	else out[idx] = base[idx] - 2 * s * u[idx] + s * s * (v[idx] - u[idx]);
+}
+__global__ void k_axpy2(const double *__restrict__ v, double *out, size_t n, double ca, double cb)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx < n) out[idx] += v[idx] * ca * cb;	/* accel_em.c:387-393: v * Ainv * cutu */
+}
+__global__ void k_add(const double *__restrict__ a, const double *__restrict__ b, double *out, size_t n)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx < n) out[idx] = a[idx] + b[idx];
+}
+
+/* ------------------------------------------------------------------ helpers */
+static inline unsigned nblk(size_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b); }
+
+static int check_slot(mchip_context *ctx, int slot)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	if (!ctx->K) return fail(ctx, MCHIP_ERR_STATE, "no model set%s", nullptr);
+	if (slot < 0 || slot > 2) return fail(ctx, MCHIP_ERR_INVALID, "slot out of range%s", nullptr);
+	return MCHIP_OK;
+}
+
+static void prof_mark(mchip_context *ctx, int kind, bool start)
+{
+	if (!ctx->profiling) return;
+	if (ctx->ev_used >= ctx->ev_pool.size()) {
+		hipEvent_t e;
+		if (hipEventCreate(&e) != hipSuccess) return;
+		ctx->ev_pool.push_back(e);
+	}
+	(void)hipEventRecord(ctx->ev_pool[ctx->ev_used++], ctx->stream);
+	if (start) ctx->ev_kind.push_back(kind);
+}
+
+static void free_model(mchip_context *ctx)
+{
+	for (int s = 0; s < 3; s++) { dfree(ctx->d_p[s]); dfree(ctx->d_q[s]); }
+	for (int s = 0; s < MCHIP_MAX_SECANTS; s++) { dfree(ctx->d_up[s]); dfree(ctx->d_vp[s]); dfree(ctx->d_uq[s]); dfree(ctx->d_vq[s]); }
+	dfree(ctx->d_sik); dfree(ctx->d_stage); dfree(ctx->d_Apart); dfree(ctx->d_Spart); dfree(ctx->d_llpart);
+	dfree(ctx->d_redpart); dfree(ctx->d_flags);
+	ctx->K = 0;
+	ctx->kt = nullptr;
+	ctx->have_ll = 0;
+}
+
+static void free_data(mchip_context *ctx)
+{
+	dfree(ctx->d_ua); dfree(ctx->d_toff); dfree(ctx->d_col_locus); dfree(ctx->d_col_allele);
+	dfree(ctx->d_gtA); dfree(ctx->d_gtS); dfree(ctx->d_asA); dfree(ctx->d_asS);
+	ctx->I = ctx->L = ctx->T = 0;
+}
+
+static mchip_pass_args pass_args(mchip_context *ctx, int slot)
+{
+	mchip_pass_args a;
+	memset(&a, 0, sizeof a);
+	a.I = ctx->I; a.L = ctx->L; a.T = ctx->T; a.ploidy = ctx->ploidy; a.K = ctx->K;
+	a.gtA = ctx->d_gtA; a.gtS = ctx->d_gtS;
+	a.ua = ctx->d_ua; a.toff = ctx->d_toff; a.col_locus = ctx->d_col_locus; a.col_allele = ctx->d_col_allele;
+	a.P = ctx->d_p[slot]; a.Q = ctx->d_q[slot]; a.qstride = ctx->qstride;
+	a.ichunk = ctx->ichunk; a.n_ichunks = ctx->n_ichunks; a.Apart = ctx->d_Apart; a.llpart = ctx->d_llpart;
+	a.flush_every = ctx->flush_every;
+	a.lchunk = ctx->lchunk; a.n_lchunks = ctx->n_lchunks; a.Spart = ctx->d_Spart;
+	a.asA = ctx->d_asA; a.asS = ctx->d_asS;
+	return a;
+}
+
+/* ------------------------------------------------------------------ C-ABI */
+extern "C" {
+
+int mchip_abi_version(void) { return MCHIP_ABI_VERSION; }
+
+int mchip_device_count(int *count)
+{
+	if (!count) return MCHIP_ERR_INVALID;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+	*count = n;
+	return MCHIP_OK;
+}
+
+int mchip_create(mchip_context **out, int device)
+{
+	if (!out) return MCHIP_ERR_INVALID;
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MCHIP_ERR_NO_DEVICE;
+	if (device < 0 || device >= n) return MCHIP_ERR_INVALID;
+	mchip_context *ctx = new mchip_context();
+	ctx->device = device;
+	ctx->err[0] = 0;
+	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+		delete ctx;
+		return MCHIP_ERR_HIP;
+	}
+	hipDeviceProp_t prop;
+	ctx->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
+	if (hipHostMalloc((void **)&ctx->h_pinned, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+	    hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(double)) != hipSuccess ||
+	    hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
+		delete ctx;
+		return MCHIP_ERR_ALLOC;
+	}
+	*out = ctx;
+	return MCHIP_OK;
+}
+
+int mchip_destroy(mchip_context *ctx)
+{
+	if (!ctx) return MCHIP_OK;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	free_model(ctx);
+	free_data(ctx);
+	dfree(ctx->d_scalars);
+	if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+	(void)hipEventDestroy(ctx->ev_begin);
+	(void)hipEventDestroy(ctx->ev_end);
+	(void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+	return MCHIP_OK;
+}
+
+const char *mchip_last_error(const mchip_context *ctx) { return ctx ? ctx->err : "null context"; }
+
+int mchip_synchronize(mchip_context *ctx)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+
+int mchip_device_info(mchip_context *ctx, char *name, int name_len, int *compute_units, double *hbm_bytes)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+	if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+	if (compute_units) *compute_units = prop.multiProcessorCount;
+	if (hbm_bytes) *hbm_bytes = (double)prop.totalGlobalMem;
+	return MCHIP_OK;
+}
+
+int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, const uint8_t *geno)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	if (I <= 0 || L <= 0 || ploidy <= 0 || ploidy > 64 || !ua || !geno)
+		return fail(ctx, MCHIP_ERR_INVALID, "set_genotypes: bad shape or null pointer%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	free_model(ctx);	/* workspaces depend on T */
+	free_data(ctx);
+
+	std::vector<int32_t> toff(L + 1);
+	toff[0] = 0;
+	int maxM = 0;
+	for (int l = 0; l < L; l++) {
+		if (ua[l] < 0 || ua[l] > 255) return fail(ctx, MCHIP_ERR_INVALID, "uniquealleles[l] must be in [0,255]%s", nullptr);
+		if ((long long)toff[l] + ua[l] > 2000000000LL) return fail(ctx, MCHIP_ERR_INVALID, "too many allele columns%s", nullptr);
+		toff[l + 1] = toff[l] + ua[l];
+		if (ua[l] > maxM) maxM = ua[l];
+	}
+	const int T = toff[L];
+	if (T <= 0) return fail(ctx, MCHIP_ERR_INVALID, "no alleles%s", nullptr);
+	std::vector<int32_t> col_locus(T);
+	std::vector<uint8_t> col_allele(T);
+	for (int l = 0; l < L; l++)
+		for (int m = 0; m < ua[l]; m++) {
+			col_locus[toff[l] + m] = l;
+			col_allele[toff[l] + m] = (uint8_t)m;
+		}
+	ctx->I = I; ctx->L = L; ctx->ploidy = ploidy; ctx->T = T; ctx->max_M = maxM;
+	const size_t raw_bytes = (size_t)I * L * ploidy;
+	ctx->geno_bytes_A = (size_t)((I + 7) / 8) * L * 8 * ploidy;
+	ctx->geno_bytes_S = (size_t)((L + 7) / 8) * I * 8 * ploidy;
+	uint8_t *d_raw = nullptr;
+	int *d_bad = nullptr;
+	HIPCHK(hipMalloc((void **)&ctx->d_ua, sizeof(int32_t) * L));
+	HIPCHK(hipMalloc((void **)&ctx->d_toff, sizeof(int32_t) * (L + 1)));
+	HIPCHK(hipMalloc((void **)&ctx->d_col_locus, sizeof(int32_t) * T));
+	HIPCHK(hipMalloc((void **)&ctx->d_col_allele, T));
+	HIPCHK(hipMalloc((void **)&ctx->d_gtA, ctx->geno_bytes_A));
+	HIPCHK(hipMalloc((void **)&ctx->d_gtS, ctx->geno_bytes_S));
+	HIPCHK(hipMalloc((void **)&d_raw, raw_bytes));
+	HIPCHK(hipMalloc((void **)&d_bad, sizeof(int)));
+	HIPCHK(hipMemcpyAsync(ctx->d_ua, ua, sizeof(int32_t) * L, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipMemcpyAsync(ctx->d_toff, toff.data(), sizeof(int32_t) * (L + 1), hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipMemcpyAsync(ctx->d_col_locus, col_locus.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipMemcpyAsync(ctx->d_col_allele, col_allele.data(), T, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipMemcpyAsync(d_raw, geno, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
+	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_raw, I, L, ploidy, ctx->d_ua, 0,
+			   ctx->d_gtA, ctx->d_gtS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
+	HIPCHK(hipGetLastError());
+	int bad = 0;
+	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	(void)hipFree(d_raw);
+	(void)hipFree(d_bad);
+	if (bad) {
+		free_data(ctx);
+		return fail(ctx, MCHIP_ERR_INVALID, "genotype allele index >= uniquealleles[l]%s", nullptr);
+	}
+	return MCHIP_OK;
+}
+
+int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constrained, int do_projection,
+		    double eta_lb, double p_lb, int n_secants)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "set_model before set_genotypes%s", nullptr);
+	if (K < 1) return fail(ctx, MCHIP_ERR_INVALID, "K must be >= 1%s", nullptr);
+	if (K > MCHIP_MAX_K) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "K > MCHIP_MAX_K is not built%s", nullptr);
+	if (!admixture) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "mixture model kernels are not built yet%s", nullptr);
+	if (n_secants < 0 || n_secants > MCHIP_MAX_SECANTS) return fail(ctx, MCHIP_ERR_INVALID, "n_secants out of range%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	free_model(ctx);
+	ctx->K = K; ctx->admixture = admixture; ctx->constrained = eta_constrained ? 1 : 0;
+	ctx->do_projection = do_projection; ctx->eta_lb = eta_lb; ctx->p_lb = p_lb; ctx->nsec = n_secants;
+	ctx->kt = mchip_get_ktable(K);
+	const int shared_eta = (!admixture || eta_constrained);
+	ctx->nq = shared_eta ? K : ctx->I * K;
+	ctx->qstride = shared_eta ? 0 : K;
+	const size_t KT = (size_t)K * ctx->T;
+	for (int s = 0; s < 3; s++) {
+		HIPCHK(hipMalloc((void **)&ctx->d_p[s], KT * sizeof(double)));
+		HIPCHK(hipMalloc((void **)&ctx->d_q[s], (size_t)ctx->nq * sizeof(double)));
+		HIPCHK(hipMemsetAsync(ctx->d_p[s], 0, KT * sizeof(double), ctx->stream));
+		HIPCHK(hipMemsetAsync(ctx->d_q[s], 0, (size_t)ctx->nq * sizeof(double), ctx->stream));
+	}
+	for (int s = 0; s < n_secants; s++) {
+		HIPCHK(hipMalloc((void **)&ctx->d_up[s], KT * sizeof(double)));
+		HIPCHK(hipMalloc((void **)&ctx->d_vp[s], KT * sizeof(double)));
+		HIPCHK(hipMalloc((void **)&ctx->d_uq[s], (size_t)ctx->nq * sizeof(double)));
+		HIPCHK(hipMalloc((void **)&ctx->d_vq[s], (size_t)ctx->nq * sizeof(double)));
+	}
+	HIPCHK(hipMalloc((void **)&ctx->d_sik, (size_t)ctx->I * K * sizeof(double)));
+	HIPCHK(hipMemsetAsync(ctx->d_sik, 0, (size_t)ctx->I * K * sizeof(double), ctx->stream));
+	HIPCHK(hipMalloc((void **)&ctx->d_stage, KT * sizeof(double)));
+
+	/* launch geometry: about 8 workgroups per CU for each pass, chunk sizes multiples of 8 */
+	const int target = 8 * ctx->n_cu;
+	const int col_tiles = (ctx->T + MCHIP_BLOCK - 1) / MCHIP_BLOCK;
+	int want = (target + col_tiles - 1) / col_tiles;
+	int iblocks = (ctx->I + 7) / 8;
+	if (want < 1) want = 1;
+	if (want > iblocks) want = iblocks;
+	ctx->ichunk = ((iblocks + want - 1) / want) * 8;
+	ctx->n_ichunks = (ctx->I + ctx->ichunk - 1) / ctx->ichunk;
+	const int ind_tiles = (ctx->I + 127) / 128;
+	want = (target + ind_tiles - 1) / ind_tiles;
+	int lblocks = (ctx->L + 7) / 8;
+	if (want < 1) want = 1;
+	if (want > lblocks) want = lblocks;
+	ctx->lchunk = ((lblocks + want - 1) / want) * 8;
+	ctx->n_lchunks = (ctx->L + ctx->lchunk - 1) / ctx->lchunk;
+	ctx->n_llpart = col_tiles * ctx->n_ichunks;
+	HIPCHK(hipMalloc((void **)&ctx->d_Apart, (size_t)ctx->n_ichunks * KT * sizeof(double)));
+	HIPCHK(hipMalloc((void **)&ctx->d_Spart, (size_t)ctx->n_lchunks * ctx->I * K * sizeof(double)));
+	HIPCHK(hipMalloc((void **)&ctx->d_llpart, (size_t)ctx->n_llpart * sizeof(double)));
+	HIPCHK(hipMalloc((void **)&ctx->d_redpart, (size_t)3 * 1024 * sizeof(double)));
+	if (ctx->max_M > 64) {
+		HIPCHK(hipMalloc((void **)&ctx->d_flags, KT));
+	}
+	/* log-product flush interval: with every parameter >= its lower bound, t = sum_k q_k p_k >= p_lb / K, so
+	 * `budget` multiplications keep a product that starts above 1e-100 above 1e-300. */
+	double tmin = p_lb / K;
+	int every = 1;
+	if (do_projection && tmin > 0 && tmin < 1) {
+		double mults = floor(200.0 / -log10(tmin));
+		every = (int)(mults / ctx->ploidy);
+		if (every < 1) every = 1;
+		if (every > 1 << 20) every = 1 << 20;
+	}
+	ctx->flush_every = every;
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+
+int mchip_q_length(const mchip_context *ctx, int *n)
+{
+	if (!ctx || !n || !ctx->K) return MCHIP_ERR_STATE;
+	*n = ctx->nq;
+	return MCHIP_OK;
+}
+int mchip_p_length(const mchip_context *ctx, int *n)
+{
+	if (!ctx || !n || !ctx->K) return MCHIP_ERR_STATE;
+	*n = ctx->K * ctx->T;
+	return MCHIP_OK;
+}
+
+int mchip_set_p(mchip_context *ctx, int slot, const double *p)
+{
+	int rc = check_slot(ctx, slot);
+	if (rc) return rc;
+	if (!p) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
+	const size_t KT = (size_t)ctx->K * ctx->T;
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipMemcpyAsync(ctx->d_stage, p, KT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(k_transpose_kt_to_tk, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_stage, ctx->d_p[slot], ctx->K, ctx->T);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(ctx->stream));	/* the host buffer may be reused on return */
+	return MCHIP_OK;
+}
+
+int mchip_get_p(mchip_context *ctx, int slot, double *p)
+{
+	int rc = check_slot(ctx, slot);
+	if (rc) return rc;
+	if (!p) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
+	const size_t KT = (size_t)ctx->K * ctx->T;
+	HIPCHK(hipSetDevice(ctx->device));
+	hipLaunchKernelGGL(k_transpose_tk_to_kt, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[slot], ctx->d_stage, ctx->K, ctx->T);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(p, ctx->d_stage, KT * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+
+int mchip_set_q(mchip_context *ctx, int slot, const double *q)
+{
+	int rc = check_slot(ctx, slot);
+	if (rc) return rc;
+	if (!q) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipMemcpyAsync(ctx->d_q[slot], q, (size_t)ctx->nq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+
+int mchip_get_q(mchip_context *ctx, int slot, double *q)
+{
+	int rc = check_slot(ctx, slot);
+	if (rc) return rc;
+	if (!q) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipMemcpyAsync(q, ctx->d_q[slot], (size_t)ctx->nq * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+
+static int fetch_scalars(mchip_context *ctx, int first, int count, double *out)
+{
+	HIPCHK(hipMemcpyAsync(ctx->h_pinned, ctx->d_scalars + first, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	for (int x = 0; x < count; x++) out[x] = ctx->h_pinned[x];
+	return MCHIP_OK;
+}
+
+/* shared eta: eta[to] = normalise(sum_i S_ik), project (em_alg.c:604-648) */
+static int finalize_shared_eta(mchip_context *ctx, int to)
+{
+	hipLaunchKernelGGL(k_column_sums, dim3(ctx->K), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_sik, ctx->I, ctx->K, ctx->d_scalars + 8);
+	hipLaunchKernelGGL(k_normalize_row, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars + 8, ctx->K, ctx->d_q[to]);
+	if (ctx->do_projection) ctx->kt->project_q(1, ctx->K, ctx->d_q[to], ctx->eta_lb, ctx->stream);
+	HIPCHK(hipGetLastError());
+	return MCHIP_OK;
+}
+
+static int run_estep(mchip_context *ctx, int from, int to, int do_mstep)
+{
+	mchip_pass_args a = pass_args(ctx, from);
+	prof_mark(ctx, MCHIP_KERN_ACCUM_P, true);
+	if (do_mstep) ctx->kt->accum_p(a, ctx->stream); else ctx->kt->loglik(a, ctx->stream);
+	prof_mark(ctx, MCHIP_KERN_ACCUM_P, false);
+	prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
+	ctx->kt->accum_q(a, ctx->stream);
+	prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
+	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_llpart, ctx->d_scalars);
+	const int indiv = ctx->qstride != 0;
+	ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[from], ctx->qstride,
+			    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, ctx->stream);
+	if (do_mstep) {
+		if (!indiv) {
+			int rc = finalize_shared_eta(ctx, to);
+			if (rc) return rc;
+		}
+		hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
+				   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
+				   1, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags);
+	}
+	HIPCHK(hipGetLastError());
+	ctx->have_ll = 1;
+	return MCHIP_OK;
+}
+
+int mchip_em_step(mchip_context *ctx, int from, int to, double *loglik)
+{
+	int rc = check_slot(ctx, from);
+	if (rc) return rc;
+	if ((rc = check_slot(ctx, to))) return rc;
+	HIPCHK(hipSetDevice(ctx->device));
+	if ((rc = run_estep(ctx, from, to, 1))) return rc;
+	if (loglik) return fetch_scalars(ctx, 0, 1, loglik);
+	return MCHIP_OK;
+}
+
+int mchip_last_loglik(mchip_context *ctx, double *loglik)
+{
+	if (!ctx || !loglik) return MCHIP_ERR_INVALID;
+	if (!ctx->have_ll) return fail(ctx, MCHIP_ERR_STATE, "no log likelihood computed yet%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	return fetch_scalars(ctx, 0, 1, loglik);
+}
+
+int mchip_e_step(mchip_context *ctx, int slot, double *loglik)
+{
+	int rc = check_slot(ctx, slot);
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(ctx->device));
+	if ((rc = run_estep(ctx, slot, slot, 0))) return rc;
+	if (loglik) return fetch_scalars(ctx, 0, 1, loglik);
+	return MCHIP_OK;
+}
+
+int mchip_loglik(mchip_context *ctx, int slot, double *loglik)
+{
+	int rc = check_slot(ctx, slot);
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(ctx->device));
+	mchip_pass_args a = pass_args(ctx, slot);
+	prof_mark(ctx, MCHIP_KERN_LOGLIK, true);
+	ctx->kt->loglik(a, ctx->stream);
+	prof_mark(ctx, MCHIP_KERN_LOGLIK, false);
+	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_llpart, ctx->d_scalars + 1);
+	HIPCHK(hipGetLastError());
+	if (loglik) return fetch_scalars(ctx, 1, 1, loglik);
+	return MCHIP_OK;
+}
+
+int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to)
+{
+	int rc = check_slot(ctx, to);
+	if (rc) return rc;
+	if (!assign) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t raw_bytes = (size_t)ctx->I * ctx->L * ctx->ploidy;
+	if (!ctx->d_asA) HIPCHK(hipMalloc((void **)&ctx->d_asA, ctx->geno_bytes_A));
+	if (!ctx->d_asS) HIPCHK(hipMalloc((void **)&ctx->d_asS, ctx->geno_bytes_S));
+	uint8_t *d_raw = nullptr;
+	int *d_bad = nullptr;
+	HIPCHK(hipMalloc((void **)&d_raw, raw_bytes));
+	HIPCHK(hipMalloc((void **)&d_bad, sizeof(int)));
+	HIPCHK(hipMemcpyAsync(d_raw, assign, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
+	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_raw, ctx->I, ctx->L, ctx->ploidy,
+			   (const int32_t *)nullptr, ctx->K, ctx->d_asA, ctx->d_asS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
+	HIPCHK(hipGetLastError());
+	int bad = 0;
+	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	(void)hipFree(d_raw);
+	(void)hipFree(d_bad);
+	if (bad) return fail(ctx, MCHIP_ERR_INVALID, "partition assignment >= K%s", nullptr);
+
+	mchip_pass_args a = pass_args(ctx, to);
+	ctx->kt->part_p(a, ctx->stream);
+	ctx->kt->part_q(a, ctx->stream);
+	const int indiv = ctx->qstride != 0;
+	ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[to], ctx->qstride,
+			    ctx->d_q[to], ctx->d_sik, indiv, 0, ctx->do_projection, ctx->eta_lb, ctx->stream);
+	if (!indiv && (rc = finalize_shared_eta(ctx, to))) return rc;
+	hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
+			   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[to], ctx->d_p[to],
+			   0, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+
+int mchip_get_expected_counts(mchip_context *ctx, double *sik)
+{
+	if (!ctx || !sik) return MCHIP_ERR_INVALID;
+	if (!ctx->K) return fail(ctx, MCHIP_ERR_STATE, "no model set%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipMemcpyAsync(sik, ctx->d_sik, (size_t)ctx->I * ctx->K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+
+/* ---- acceleration ---- */
+static int check_secant(mchip_context *ctx, int j)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	if (!ctx->K) return fail(ctx, MCHIP_ERR_STATE, "no model set%s", nullptr);
+	if (j < 0 || j >= ctx->nsec) return fail(ctx, MCHIP_ERR_INVALID, "secant index out of range%s", nullptr);
+	return MCHIP_OK;
+}
+
+int mchip_secant(mchip_context *ctx, int which, int j, int to, int from)
+{
+	int rc = check_secant(ctx, j);
+	if (rc) return rc;
+	if ((rc = check_slot(ctx, to)) || (rc = check_slot(ctx, from))) return rc;
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t KT = (size_t)ctx->K * ctx->T;
+	double *dp = which ? ctx->d_vp[j] : ctx->d_up[j];
+	double *dq = which ? ctx->d_vq[j] : ctx->d_uq[j];
+	hipLaunchKernelGGL(k_diff, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[to], ctx->d_p[from], dp, KT);
+	hipLaunchKernelGGL(k_diff, dim3(nblk(ctx->nq)), dim3(256), 0, ctx->stream, ctx->d_q[to], ctx->d_q[from], dq, (size_t)ctx->nq);
+	HIPCHK(hipGetLastError());
+	return MCHIP_OK;
+}
+
+static int dots_common(mchip_context *ctx, const double *uq, const double *vq, const double *u2q,
+		       const double *up, const double *vp, const double *u2p, int mode, int nout, double *out)
+{
+	const size_t KT = (size_t)ctx->K * ctx->T;
+	const int gq = (int)((ctx->nq + 4095) / 4096) > 512 ? 512 : (int)((ctx->nq + 4095) / 4096);
+	const int gp = (int)((KT + 4095) / 4096) > 512 ? 512 : (int)((KT + 4095) / 4096);
+	double *part_q = ctx->d_redpart, *part_p = ctx->d_redpart + 3 * 512;
+	hipLaunchKernelGGL(k_dots, dim3(gq), dim3(MCHIP_BLOCK), 0, ctx->stream, uq, vq, u2q, (size_t)ctx->nq, mode, part_q);
+	hipLaunchKernelGGL(k_dots, dim3(gp), dim3(MCHIP_BLOCK), 0, ctx->stream, up, vp, u2p, KT, mode, part_p);
+	for (int x = 0; x < nout; x++) {
+		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, part_q + (size_t)x * gq, gq, ctx->d_scalars + 16 + x);
+		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, part_p + (size_t)x * gp, gp, ctx->d_scalars + 20 + x);
+	}
+	HIPCHK(hipGetLastError());
+	double tmp[8];
+	int rc = fetch_scalars(ctx, 16, 8, tmp);
+	if (rc) return rc;
+	for (int x = 0; x < nout; x++) out[x] = tmp[x] + tmp[4 + x];	/* eta terms first, then p (accel_em.c:143-184) */
+	return MCHIP_OK;
+}
+
+int mchip_step_dots(mchip_context *ctx, int j, double *out3)
+{
+	int rc = check_secant(ctx, j);
+	if (rc) return rc;
+	if (!out3) return MCHIP_ERR_INVALID;
+	HIPCHK(hipSetDevice(ctx->device));
+	return dots_common(ctx, ctx->d_uq[j], ctx->d_vq[j], nullptr, ctx->d_up[j], ctx->d_vp[j], nullptr, 0, 3, out3);
+}
+
+int mchip_secant_dots(mchip_context *ctx, int j1, int j2, double *out2)
+{
+	int rc = check_secant(ctx, j1);
+	if (rc) return rc;
+	if ((rc = check_secant(ctx, j2))) return rc;
+	if (!out2) return MCHIP_ERR_INVALID;
+	HIPCHK(hipSetDevice(ctx->device));
+	return dots_common(ctx, ctx->d_uq[j1], ctx->d_vq[j2], ctx->d_uq[j2], ctx->d_up[j1], ctx->d_vp[j2], ctx->d_up[j2], 1, 2, out2);
+}
+
+static int project_slot(mchip_context *ctx, int to)
+{
+	if (!ctx->do_projection) return MCHIP_OK;
+	hipLaunchKernelGGL(k_project_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
+			   ctx->L, ctx->K, ctx->d_toff, ctx->d_p[to], ctx->p_lb, ctx->d_flags);
+	ctx->kt->project_q(ctx->qstride ? ctx->I : 1, ctx->K, ctx->d_q[to], ctx->eta_lb, ctx->stream);
+	HIPCHK(hipGetLastError());
+	return MCHIP_OK;
+}
+
+int mchip_accel_update(mchip_context *ctx, int to, int base, int j, double s, int qn_form)
+{
+	int rc = check_secant(ctx, j);
+	if (rc) return rc;
+	if ((rc = check_slot(ctx, to)) || (rc = check_slot(ctx, base))) return rc;
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t KT = (size_t)ctx->K * ctx->T;
+	hipLaunchKernelGGL(k_accel_update, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[base], ctx->d_up[j], ctx->d_vp[j], ctx->d_p[to], KT, s, qn_form);
+	hipLaunchKernelGGL(k_accel_update, dim3(nblk(ctx->nq)), dim3(256), 0, ctx->stream, ctx->d_q[base], ctx->d_uq[j], ctx->d_vq[j], ctx->d_q[to], (size_t)ctx->nq, s, qn_form);
+	HIPCHK(hipGetLastError());
+	return project_slot(ctx, to);
+}
+
+int mchip_multisecant_update(mchip_context *ctx, int to, int base, int u_index, int n_terms,
+			     const int *v_index, const double *coef_a, const double *coef_b)
+{
+	int rc = check_secant(ctx, u_index);
+	if (rc) return rc;
+	if ((rc = check_slot(ctx, to)) || (rc = check_slot(ctx, base))) return rc;
+	if (n_terms < 0 || (n_terms && (!v_index || !coef_a || !coef_b))) return MCHIP_ERR_INVALID;
+	for (int t = 0; t < n_terms; t++) if ((rc = check_secant(ctx, v_index[t]))) return rc;
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t KT = (size_t)ctx->K * ctx->T;
+	hipLaunchKernelGGL(k_add, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[base], ctx->d_up[u_index], ctx->d_p[to], KT);
+	hipLaunchKernelGGL(k_add, dim3(nblk(ctx->nq)), dim3(256), 0, ctx->stream, ctx->d_q[base], ctx->d_uq[u_index], ctx->d_q[to], (size_t)ctx->nq);
+	for (int t = 0; t < n_terms; t++) {
+		hipLaunchKernelGGL(k_axpy2, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_vp[v_index[t]], ctx->d_p[to], KT, coef_a[t], coef_b[t]);
+		hipLaunchKernelGGL(k_axpy2, dim3(nblk(ctx->nq)), dim3(256), 0, ctx->stream, ctx->d_vq[v_index[t]], ctx->d_q[to], (size_t)ctx->nq, coef_a[t], coef_b[t]);
+	}
+	HIPCHK(hipGetLastError());
+	return project_slot(ctx, to);
+}
+
+/* ---- measurement hooks ---- */
+int mchip_profile_begin(mchip_context *ctx)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	HIPCHK(hipSetDevice(ctx->device));
+	ctx->profiling = 1;
+	ctx->ev_used = 0;
+	ctx->ev_kind.clear();
+	HIPCHK(hipEventRecord(ctx->ev_begin, ctx->stream));
+	return MCHIP_OK;
+}
+
+int mchip_profile_end(mchip_context *ctx, double *total_ms, double *kernel_ms, int *launches)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	if (!ctx->profiling) return fail(ctx, MCHIP_ERR_STATE, "profile_end without profile_begin%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipEventRecord(ctx->ev_end, ctx->stream));
+	HIPCHK(hipEventSynchronize(ctx->ev_end));
+	ctx->profiling = 0;
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+	if (total_ms) *total_ms = ms;
+	double km[MCHIP_KERN_COUNT] = {0, 0, 0};
+	int kl[MCHIP_KERN_COUNT] = {0, 0, 0};
+	for (size_t p = 0; 2 * p + 1 < ctx->ev_used && p < ctx->ev_kind.size(); p++) {
+		HIPCHK(hipEventElapsedTime(&ms, ctx->ev_pool[2 * p], ctx->ev_pool[2 * p + 1]));
+		km[ctx->ev_kind[p]] += ms;
+		kl[ctx->ev_kind[p]]++;
+	}
+	for (int x = 0; x < MCHIP_KERN_COUNT; x++) {
+		if (kernel_ms) kernel_ms[x] = km[x];
+		if (launches) launches[x] = kl[x];
+	}
+	return MCHIP_OK;
+}
+
+}  /* extern "C" */

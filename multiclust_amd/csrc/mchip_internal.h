@@ -1,0 +1,62 @@
+/*
+ * mchip_internal.h -- private definitions shared by the HIP translation units of libmulticlust_hip.so.
+ * Not part of the C-ABI (include/multiclust_hip.h is).
+ *
+ * Device data layout (all sized for one MI355X, 288 GB HBM3E):
+ *   gtA  uint8 [ceil(I/8)][L][8][ploidy]   genotype blocked by 8 individuals: one 8*ploidy-byte load per lane
+ *                                           (lane = allele column) serves 8 individuals of the column pass
+ *   gtS  uint8 [ceil(L/8)][I][8][ploidy]   genotype blocked by 8 loci: one load per lane (lane = individual)
+ *                                           serves 8 loci of the individual pass
+ *   P    double [T][K]  per slot           allele column c = T_off[l]+m, K contiguous doubles per column
+ *   Q    double [I][K]  per slot           (or [K] when eta is shared: row stride 0)
+ *   col_locus int32 [T], col_allele uint8 [T], toff int32 [L+1], ua int32 [L]
+ */
+#ifndef MCHIP_INTERNAL_H
+#define MCHIP_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+#include "multiclust_hip.h"
+
+#define MCHIP_BLOCK 256
+
+enum { MCHIP_KERN_ACCUM_P = 0, MCHIP_KERN_ACCUM_Q = 1, MCHIP_KERN_LOGLIK = 2, MCHIP_KERN_COUNT = 3 };
+
+/* arguments of the two streaming passes over the genotype matrix */
+struct mchip_pass_args {
+	int I, L, T, ploidy, K;
+	const uint8_t *gtA, *gtS;
+	const int32_t *ua, *toff, *col_locus;
+	const uint8_t *col_allele;
+	const double *P;	/* [T][K] slot read by the E step */
+	const double *Q;	/* [I][K] or [K] */
+	int qstride;		/* K, or 0 when eta is shared by all individuals */
+	/* column pass (lane = allele column, loop over a chunk of individuals) */
+	int ichunk, n_ichunks;	/* individuals per chunk (multiple of 8) */
+	double *Apart;		/* [n_ichunks][T][K] sum_i q_ik r_ic over the chunk */
+	double *llpart;		/* [gridDim.x*gridDim.y] block partial log-likelihoods */
+	int flush_every;	/* individuals between log-product flushes */
+	/* individual pass (lane = individual, loop over a chunk of loci) */
+	int lchunk, n_lchunks;	/* loci per chunk (multiple of 8) */
+	double *Spart;		/* [n_lchunks][I][K] sum_c P_kc r_ic over the chunk */
+	/* hard-partition first M step */
+	const uint8_t *asA, *asS;	/* assignment bytes in the gtA / gtS layouts */
+};
+
+/* per-K kernel table (one translation unit per K keeps each hipcc job small and `make -j` parallel) */
+struct mchip_ktable {
+	void (*accum_p)(const mchip_pass_args &a, hipStream_t s);	/* column pass: Apart + logL */
+	void (*loglik)(const mchip_pass_args &a, hipStream_t s);	/* column pass: logL only */
+	void (*accum_q)(const mchip_pass_args &a, hipStream_t s);	/* individual pass: Spart */
+	void (*part_p)(const mchip_pass_args &a, hipStream_t s);	/* hard partition, column pass */
+	void (*part_q)(const mchip_pass_args &a, hipStream_t s);	/* hard partition, individual pass */
+	/* finalize: Q[to] from Spart (normalise + project), stores expected counts */
+	void (*finalize_q)(int I, int K, int n_lchunks, const double *Spart, const double *Qfrom, int qstride_from,
+			   double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, hipStream_t s);
+	void (*project_q)(int nrows, int K, double *Q, double lb, hipStream_t s);
+};
+
+const mchip_ktable *mchip_get_ktable(int K);
+
+#endif

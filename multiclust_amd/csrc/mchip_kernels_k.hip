@@ -1,0 +1,390 @@
+/*
+ * mchip_kernels_k.hip -- the K-specialised gfx950 kernels of the admixture EM hot path.
+ * Compiled once per K (hipcc -DMCHIP_K=<K>), see Makefile; each object exports mchip_ktable_<K>.
+ *
+ * Fused E+M without materialising d_iklm (reference em_alg.c:291-486 + 592-754):
+ *   per non-empty cell (i, c=(l,m)), n = ILM[i][l][m]:
+ *       t = sum_k q_ik P_kc ; r = n / t ; logL += n log t
+ *       S_ik = q_ik * sum_c P_kc r_ic        (= sum_{l,m} d_iklm, em_alg.c:650-682)
+ *       N_kc = P_kc * sum_i q_ik r_ic        (= sum_i d_iklm,      em_alg.c:706-731)
+ * The two marginals reduce over opposite axes, so the genotype matrix is streamed by two passes whose
+ * reductions are both thread-private (no cross-lane traffic, no atomics, bitwise reproducible):
+ *   column pass     (lane = allele column c, loop over individuals): N-side sum_i q_ik r_ic, and logL;
+ *                    q_i is wave-uniform -> scalar loads, P_kc and the accumulators live in VGPRs.
+ *   individual pass (lane = individual i, loop over loci/alleles):   S-side sum_c P_kc r_ic;
+ *                    P_.c is wave-uniform -> scalar loads, q_ik and the accumulators live in VGPRs.
+ * All arithmetic is IEEE double (v_fma_f64); n log t is accumulated as log of a running product of t
+ * (one v_log-free multiply per allele copy, one log per flush), see DESIGN.md.
+ */
+#include "mchip_internal.h"
+
+#ifndef MCHIP_K
+#error "compile with -DMCHIP_K=<K>"
+#endif
+
+namespace {
+
+constexpr int K = MCHIP_K;
+
+/* 1/t to full double precision for t in (0, 1]: hardware seed + two Newton steps (the same recipe the
+ * compiler uses inside its IEEE divide, without the scaling/fix-up that denormal or huge inputs need). */
+__device__ __forceinline__ double rcp_full(double t)
+{
+	double r = __builtin_amdgcn_rcp(t);
+	double e = __builtin_fma(-t, r, 1.0);
+	r = __builtin_fma(r, e, r);
+	e = __builtin_fma(-t, r, 1.0);
+	r = __builtin_fma(r, e, r);
+	return r;
+}
+
+/* genotype bytes of sub-entry j (0..7) of an 8-entry group; PL = 2 fast path keeps the group in a uint4 */
+template <int PL> struct geno_group;
+
+template <> struct geno_group<2> {
+	uint4 g;
+	__device__ __forceinline__ void load(const uint8_t *base, size_t group, int) { g = *reinterpret_cast<const uint4 *>(base + group * 16); }
+	__device__ __forceinline__ unsigned field(int j) const
+	{
+		unsigned w = (j < 2) ? g.x : (j < 4) ? g.y : (j < 6) ? g.z : g.w;
+		return (w >> ((j & 1) * 16)) & 0xFFFFu;
+	}
+	/* number of copies of entry j equal to allele m */
+	__device__ __forceinline__ int count(int j, unsigned m, int) const
+	{
+		unsigned w = field(j);
+		return (int)((w & 0xFFu) == m) + (int)((w >> 8) == m);
+	}
+	__device__ __forceinline__ unsigned copy(int j, int a, int) const { return (field(j) >> (8 * a)) & 0xFFu; }
+};
+
+template <> struct geno_group<0> {	/* any ploidy: byte loads */
+	const uint8_t *p;
+	__device__ __forceinline__ void load(const uint8_t *base, size_t group, int pl) { p = base + group * 8 * (size_t)pl; }
+	__device__ __forceinline__ int count(int j, unsigned m, int pl) const
+	{
+		int n = 0;
+		for (int a = 0; a < pl; a++) n += (int)(p[j * pl + a] == m);
+		return n;
+	}
+	__device__ __forceinline__ unsigned copy(int j, int a, int pl) const { return p[j * pl + a]; }
+};
+
+__device__ __forceinline__ double block_sum_256(double v, double *red)
+{
+	const int tid = threadIdx.x;
+	red[tid] = v;
+	__syncthreads();
+	for (int s = 128; s > 0; s >>= 1) {
+		if (tid < s) red[tid] += red[tid + s];
+		__syncthreads();
+	}
+	return red[0];
+}
+
+/* ---------------------------------------------------------------- column pass */
+template <int PL, bool ACCUM>
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_column_pass(mchip_pass_args a)
+{
+	__shared__ double red[MCHIP_BLOCK];
+	const int c_raw = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
+	const bool valid = c_raw < a.T;
+	const int c = valid ? c_raw : a.T - 1;
+	const int l = a.col_locus[c];
+	const unsigned m = valid ? (unsigned)a.col_allele[c] : 0xFEu;	/* 0xFE never matches a genotype byte */
+	const int pl = PL ? PL : a.ploidy;
+
+	double p[K], acc[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+		p[k] = a.P[(size_t)c * K + k];
+		acc[k] = 0.0;
+	}
+	const int i0 = blockIdx.y * a.ichunk;
+	const int i1 = min(a.I, i0 + a.ichunk);
+	double ll = 0.0, prod = 1.0;
+	int cnt = 0;
+
+	for (int ib = i0 >> 3; ib < ((i1 + 7) >> 3); ib++) {
+		geno_group<PL> g;
+		g.load(a.gtA, (size_t)ib * a.L + l, pl);
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const int i = min(ib * 8 + j, a.I - 1);	/* padded individuals carry 0xFF bytes: n = 0 */
+			const double *__restrict__ q = a.Q + (size_t)i * a.qstride;	/* wave-uniform: s_load */
+			const int n = g.count(j, m, pl);
+			double t = q[0] * p[0];
+#pragma unroll
+			for (int k = 1; k < K; k++) t = __builtin_fma(q[k], p[k], t);
+			if (ACCUM) {
+				const double r = (double)n * rcp_full(t);
+#pragma unroll
+				for (int k = 0; k < K; k++) acc[k] = __builtin_fma(q[k], r, acc[k]);
+			}
+			/* n log t as log of a product: t^n */
+			if (PL == 2) {
+				prod *= (n >= 1) ? t : 1.0;
+				prod *= (n >= 2) ? t : 1.0;
+			} else {
+				for (int b = 1; b <= pl; b++) prod *= (n >= b) ? t : 1.0;
+			}
+			if (++cnt >= a.flush_every) {
+				cnt = 0;
+				if (prod < 1e-100) {
+					ll += log(prod);
+					prod = 1.0;
+				}
+			}
+		}
+	}
+	ll += log(prod);
+	if (ACCUM && valid) {
+		double *out = a.Apart + ((size_t)blockIdx.y * a.T + c) * K;
+#pragma unroll
+		for (int k = 0; k < K; k++) out[k] = acc[k];
+	}
+	const double tot = block_sum_256(ll, red);
+	if (threadIdx.x == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+/* ---------------------------------------------------------------- individual pass */
+constexpr int QBLOCK = 128;
+
+template <int PL>
+__global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
+{
+	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
+	const bool active = i_raw < a.I;
+	const int i = active ? i_raw : a.I - 1;
+	const int pl = PL ? PL : a.ploidy;
+	double q[K], acc[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+		q[k] = a.Q[(size_t)i * a.qstride + k];
+		acc[k] = 0.0;
+	}
+	const int l0 = blockIdx.y * a.lchunk;
+	const int l1 = min(a.L, l0 + a.lchunk);
+	for (int lb = l0 >> 3; lb < ((l1 + 7) >> 3); lb++) {
+		geno_group<PL> g;
+		g.load(a.gtS, (size_t)lb * a.I + i, pl);
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const int l = lb * 8 + j;
+			if (l >= l1) break;			/* wave-uniform */
+			const int c0 = a.toff[l];
+			const int M = a.ua[l];
+			for (int m = 0; m < M; m++) {
+				const int n = active ? g.count(j, (unsigned)m, pl) : 0;
+				if (__ballot(n > 0) == 0ull) continue;	/* nobody in this wave carries allele m */
+				const double *__restrict__ pc = a.P + (size_t)(c0 + m) * K;	/* wave-uniform: s_load */
+				double t = q[0] * pc[0];
+#pragma unroll
+				for (int k = 1; k < K; k++) t = __builtin_fma(q[k], pc[k], t);
+				const double r = (double)n * rcp_full(t);
+#pragma unroll
+				for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[k], r, acc[k]);
+			}
+		}
+	}
+	if (active) {
+		double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
+#pragma unroll
+		for (int k = 0; k < K; k++) out[k] = acc[k];
+	}
+}
+
+/* ---------------------------------------------------------------- hard partition (first M step)
+ * rnd_init.c:456-482: d[i][k][l][m] = 1 for every copy a of allele m assigned to cluster k. */
+template <int PL>
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_partition_columns(mchip_pass_args a)
+{
+	const int c_raw = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
+	const bool valid = c_raw < a.T;
+	const int c = valid ? c_raw : a.T - 1;
+	const int l = a.col_locus[c];
+	const unsigned m = valid ? (unsigned)a.col_allele[c] : 0xFEu;
+	const int pl = PL ? PL : a.ploidy;
+	double acc[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) acc[k] = 0.0;
+	const int i0 = blockIdx.y * a.ichunk;
+	const int i1 = min(a.I, i0 + a.ichunk);
+	for (int ib = i0 >> 3; ib < ((i1 + 7) >> 3); ib++) {
+		geno_group<PL> g, s;
+		g.load(a.gtA, (size_t)ib * a.L + l, pl);
+		s.load(a.asA, (size_t)ib * a.L + l, pl);
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			unsigned flags = 0;
+			for (int b = 0; b < pl; b++)
+				if (g.copy(j, b, pl) == m) flags |= 1u << (s.copy(j, b, pl) & 31u);
+#pragma unroll
+			for (int k = 0; k < K; k++) acc[k] += (double)((flags >> k) & 1u);
+		}
+	}
+	if (valid) {
+		double *out = a.Apart + ((size_t)blockIdx.y * a.T + c) * K;
+#pragma unroll
+		for (int k = 0; k < K; k++) out[k] = acc[k];
+	}
+}
+
+template <int PL>
+__global__ __launch_bounds__(QBLOCK) void k_partition_individuals(mchip_pass_args a)
+{
+	const int i = blockIdx.x * QBLOCK + threadIdx.x;
+	if (i >= a.I) return;
+	const int pl = PL ? PL : a.ploidy;
+	double acc[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) acc[k] = 0.0;
+	const int l0 = blockIdx.y * a.lchunk;
+	const int l1 = min(a.L, l0 + a.lchunk);
+	for (int lb = l0 >> 3; lb < ((l1 + 7) >> 3); lb++) {
+		geno_group<PL> g, s;
+		g.load(a.gtS, (size_t)lb * a.I + i, pl);
+		s.load(a.asS, (size_t)lb * a.I + i, pl);
+		for (int j = 0; j < 8; j++) {
+			if (lb * 8 + j >= l1) break;
+			for (int b = 0; b < pl; b++) {
+				const unsigned mb = g.copy(j, b, pl), kb = s.copy(j, b, pl);
+				if (mb == MCHIP_MISSING) continue;
+				bool dup = false;
+				for (int b2 = 0; b2 < b; b2++)
+					dup |= (g.copy(j, b2, pl) == mb) && (s.copy(j, b2, pl) == kb);
+				if (dup) continue;
+#pragma unroll
+				for (int k = 0; k < K; k++) acc[k] += (kb == (unsigned)k) ? 1.0 : 0.0;
+			}
+		}
+	}
+	double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
+#pragma unroll
+	for (int k = 0; k < K; k++) out[k] = acc[k];
+}
+
+/* ---------------------------------------------------------------- simplex.c:109-143 on K registers */
+__device__ __forceinline__ void michelot_k(double (&x)[K], double mn)
+{
+	unsigned fixed = 0;
+	int n = K;
+	while (n) {
+		double csum = 0.0;
+#pragma unroll
+		for (int j = 0; j < K; j++) csum += x[j];
+		const double shift = (csum - 1.0) / (double)n;
+		bool can_terminate = true;
+#pragma unroll
+		for (int j = 0; j < K; j++)
+			if (!((fixed >> j) & 1u)) {
+				x[j] -= shift;
+				if (x[j] < mn) {
+					x[j] = mn;
+					fixed |= 1u << j;
+					n--;
+					can_terminate = false;
+				}
+			}
+		if (can_terminate) break;
+	}
+}
+
+/* Q[to][i][.] = normalise(q_ik * sum_chunks Spart) then project (em_alg.c:685-701); also stores the
+ * expected counts S_ik the writers need (write_file.c:359-381). */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_q(int I, int n_lchunks, const double *__restrict__ Spart,
+		const double *__restrict__ Qfrom, int qstride_from, double *Qto, double *sik,
+		int do_mstep, int weighted, int do_projection, double lb)
+{
+	const int i = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
+	if (i >= I) return;
+	double s[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) s[k] = 0.0;
+	for (int ch = 0; ch < n_lchunks; ch++) {
+		const double *src = Spart + ((size_t)ch * I + i) * K;
+#pragma unroll
+		for (int k = 0; k < K; k++) s[k] += src[k];
+	}
+	if (weighted) {
+#pragma unroll
+		for (int k = 0; k < K; k++) s[k] *= Qfrom[(size_t)i * qstride_from + k];
+	}
+#pragma unroll
+	for (int k = 0; k < K; k++) sik[(size_t)i * K + k] = s[k];
+	if (!do_mstep) return;
+	double temp = 0.0;
+#pragma unroll
+	for (int k = 0; k < K; k++) temp += s[k];
+#pragma unroll
+	for (int k = 0; k < K; k++) s[k] /= temp;
+	if (do_projection) michelot_k(s, lb);
+#pragma unroll
+	for (int k = 0; k < K; k++) Qto[(size_t)i * K + k] = s[k];
+}
+
+/* projection of nrows rows of K (accelerated updates, accel_em.c:510-511; shared eta row) */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_project_q(int nrows, double *Q, double lb)
+{
+	const int i = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
+	if (i >= nrows) return;
+	double s[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) s[k] = Q[(size_t)i * K + k];
+	michelot_k(s, lb);
+#pragma unroll
+	for (int k = 0; k < K; k++) Q[(size_t)i * K + k] = s[k];
+}
+
+/* ---------------------------------------------------------------- launchers */
+inline dim3 column_grid(const mchip_pass_args &a) { return dim3((a.T + MCHIP_BLOCK - 1) / MCHIP_BLOCK, a.n_ichunks); }
+inline dim3 indiv_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK - 1) / QBLOCK, a.n_lchunks); }
+
+void launch_accum_p(const mchip_pass_args &a, hipStream_t s)
+{
+	if (a.ploidy == 2) hipLaunchKernelGGL((k_column_pass<2, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+	else hipLaunchKernelGGL((k_column_pass<0, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+}
+void launch_loglik(const mchip_pass_args &a, hipStream_t s)
+{
+	if (a.ploidy == 2) hipLaunchKernelGGL((k_column_pass<2, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+	else hipLaunchKernelGGL((k_column_pass<0, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+}
+void launch_accum_q(const mchip_pass_args &a, hipStream_t s)
+{
+	if (a.ploidy == 2) hipLaunchKernelGGL((k_individual_pass<2>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
+	else hipLaunchKernelGGL((k_individual_pass<0>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
+}
+void launch_part_p(const mchip_pass_args &a, hipStream_t s)
+{
+	if (a.ploidy == 2) hipLaunchKernelGGL((k_partition_columns<2>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+	else hipLaunchKernelGGL((k_partition_columns<0>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+}
+void launch_part_q(const mchip_pass_args &a, hipStream_t s)
+{
+	if (a.ploidy == 2) hipLaunchKernelGGL((k_partition_individuals<2>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
+	else hipLaunchKernelGGL((k_partition_individuals<0>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
+}
+void launch_finalize_q(int I, int, int n_lchunks, const double *Spart, const double *Qfrom, int qstride_from,
+		       double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_finalize_q, dim3((I + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s,
+			   I, n_lchunks, Spart, Qfrom, qstride_from, Qto, sik, do_mstep, weighted, do_projection, lb);
+}
+void launch_project_q(int nrows, int, double *Q, double lb, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_project_q, dim3((nrows + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s, nrows, Q, lb);
+}
+
+}  // namespace
+
+#define MCHIP_CAT2(a, b) a##b
+#define MCHIP_CAT(a, b) MCHIP_CAT2(a, b)
+/* a function, not a const global: hipcc would try to emit a const table of host pointers on the device side */
+const mchip_ktable *MCHIP_CAT(mchip_ktable_get_, MCHIP_K)()
+{
+	static mchip_ktable t = {
+		launch_accum_p, launch_loglik, launch_accum_q, launch_part_p, launch_part_q, launch_finalize_q, launch_project_q,
+	};
+	return &t;
+}

@@ -1,0 +1,212 @@
+"""ctypes view of include/multiclust_hip.h (libmulticlust_hip.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PROF_KINDS = 3
+STATUS = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "ALLOC", 5: "STATE", 6: "UNSUPPORTED"}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libmulticlust_hip.so")
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library. Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise HipError("%s is missing: run `make` (or __graft_entry__.build()); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    vp, dp, i32 = C.c_void_p, C.POINTER(C.c_double), C.c_int
+    ip = C.POINTER(C.c_int)
+    sig = {
+        "mchip_abi_version": ([], i32),
+        "mchip_device_count": ([ip], i32),
+        "mchip_create": ([C.POINTER(vp), i32], i32),
+        "mchip_destroy": ([vp], i32),
+        "mchip_last_error": ([vp], C.c_char_p),
+        "mchip_synchronize": ([vp], i32),
+        "mchip_set_genotypes": ([vp, i32, i32, i32, vp, vp], i32),
+        "mchip_set_model": ([vp, i32, i32, i32, i32, C.c_double, C.c_double, i32], i32),
+        "mchip_set_p": ([vp, i32, vp], i32),
+        "mchip_get_p": ([vp, i32, vp], i32),
+        "mchip_set_q": ([vp, i32, vp], i32),
+        "mchip_get_q": ([vp, i32, vp], i32),
+        "mchip_q_length": ([vp, ip], i32),
+        "mchip_p_length": ([vp, ip], i32),
+        "mchip_em_step": ([vp, i32, i32, dp], i32),
+        "mchip_last_loglik": ([vp, dp], i32),
+        "mchip_e_step": ([vp, i32, dp], i32),
+        "mchip_loglik": ([vp, i32, dp], i32),
+        "mchip_mstep_from_partition": ([vp, vp, i32], i32),
+        "mchip_get_expected_counts": ([vp, vp], i32),
+        "mchip_secant": ([vp, i32, i32, i32, i32], i32),
+        "mchip_step_dots": ([vp, i32, dp], i32),
+        "mchip_secant_dots": ([vp, i32, i32, dp], i32),
+        "mchip_accel_update": ([vp, i32, i32, i32, C.c_double, i32], i32),
+        "mchip_multisecant_update": ([vp, i32, i32, i32, i32, ip, dp, dp], i32),
+        "mchip_profile_begin": ([vp], i32),
+        "mchip_profile_end": ([vp, dp, dp, ip], i32),
+        "mchip_device_info": ([vp, C.c_char_p, i32, ip, dp], i32),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)        # AttributeError here = the library does not export its own header
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+ABI_SYMBOLS = [
+    "mchip_abi_version", "mchip_device_count", "mchip_create", "mchip_destroy", "mchip_last_error",
+    "mchip_synchronize", "mchip_set_genotypes", "mchip_set_model", "mchip_set_p", "mchip_get_p", "mchip_set_q",
+    "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_last_loglik", "mchip_e_step",
+    "mchip_loglik", "mchip_mstep_from_partition", "mchip_get_expected_counts", "mchip_secant", "mchip_step_dots",
+    "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
+    "mchip_profile_end", "mchip_device_info",
+]
+
+
+class Context:
+    """One HIP context = one stream + device buffers for (device, data set, K)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.mchip_create(C.byref(self.h), device)
+        if rc:
+            raise HipError("mchip_create failed: %s (no GPU => no product path; nothing falls back to the CPU)" % STATUS.get(rc, rc))
+        self.I = self.L = self.ploidy = self.T = self.K = 0
+        self.indiv_q = True
+
+    def _chk(self, rc):
+        if rc:
+            raise HipError("%s: %s" % (STATUS.get(rc, rc), self.lib.mchip_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.mchip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_genotypes(self, ua, geno):
+        geno = np.ascontiguousarray(geno, dtype=np.uint8)
+        ua = np.ascontiguousarray(ua, dtype=np.int32)
+        I, L, p = geno.shape
+        self._chk(self.lib.mchip_set_genotypes(self.h, I, L, p, ua.ctypes.data, geno.ctypes.data))
+        self.I, self.L, self.ploidy, self.T = I, L, p, int(ua.sum())
+
+    def set_model(self, K, admixture=1, eta_constrained=0, do_projection=1, lower_bound=1e-8, n_secants=1):
+        self._chk(self.lib.mchip_set_model(self.h, K, admixture, eta_constrained, do_projection,
+                                           lower_bound, lower_bound, n_secants))
+        self.K = K
+        self.indiv_q = bool(admixture and not eta_constrained)
+
+    def set_p(self, slot, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        assert p.size == self.K * self.T
+        self._chk(self.lib.mchip_set_p(self.h, slot, p.ctypes.data))
+
+    def get_p(self, slot):
+        p = np.empty((self.K, self.T), dtype=np.float64)
+        self._chk(self.lib.mchip_get_p(self.h, slot, p.ctypes.data))
+        return p
+
+    def set_q(self, slot, q):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        assert q.size == (self.I * self.K if self.indiv_q else self.K)
+        self._chk(self.lib.mchip_set_q(self.h, slot, q.ctypes.data))
+
+    def get_q(self, slot):
+        q = np.empty((self.I, self.K) if self.indiv_q else (self.K,), dtype=np.float64)
+        self._chk(self.lib.mchip_get_q(self.h, slot, q.ctypes.data))
+        return q
+
+    def em_step(self, frm=0, to=0, sync=True):
+        if not sync:
+            self._chk(self.lib.mchip_em_step(self.h, frm, to, None))
+            return None
+        ll = C.c_double()
+        self._chk(self.lib.mchip_em_step(self.h, frm, to, C.byref(ll)))
+        return ll.value
+
+    def last_loglik(self):
+        ll = C.c_double()
+        self._chk(self.lib.mchip_last_loglik(self.h, C.byref(ll)))
+        return ll.value
+
+    def e_step(self, slot=0):
+        ll = C.c_double()
+        self._chk(self.lib.mchip_e_step(self.h, slot, C.byref(ll)))
+        return ll.value
+
+    def loglik(self, slot=0, sync=True):
+        if not sync:
+            self._chk(self.lib.mchip_loglik(self.h, slot, None))
+            return None
+        ll = C.c_double()
+        self._chk(self.lib.mchip_loglik(self.h, slot, C.byref(ll)))
+        return ll.value
+
+    def mstep_from_partition(self, assign, to=0):
+        a = np.ascontiguousarray(assign, dtype=np.uint8)
+        assert a.size == self.I * self.L * self.ploidy
+        self._chk(self.lib.mchip_mstep_from_partition(self.h, a.ctypes.data, to))
+
+    def expected_counts(self):
+        s = np.empty((self.I, self.K), dtype=np.float64)
+        self._chk(self.lib.mchip_get_expected_counts(self.h, s.ctypes.data))
+        return s
+
+    def secant(self, which, j, to, frm):
+        self._chk(self.lib.mchip_secant(self.h, which, j, to, frm))
+
+    def step_dots(self, j):
+        out = (C.c_double * 3)()
+        self._chk(self.lib.mchip_step_dots(self.h, j, out))
+        return list(out)
+
+    def secant_dots(self, j1, j2):
+        out = (C.c_double * 2)()
+        self._chk(self.lib.mchip_secant_dots(self.h, j1, j2, out))
+        return list(out)
+
+    def accel_update(self, to, base, j, s, qn_form=0):
+        self._chk(self.lib.mchip_accel_update(self.h, to, base, j, s, qn_form))
+
+    def synchronize(self):
+        self._chk(self.lib.mchip_synchronize(self.h))
+
+    def profile_begin(self):
+        self._chk(self.lib.mchip_profile_begin(self.h))
+
+    def profile_end(self):
+        total = C.c_double()
+        km = (C.c_double * PROF_KINDS)()
+        kl = (C.c_int * PROF_KINDS)()
+        self._chk(self.lib.mchip_profile_end(self.h, C.byref(total), km, kl))
+        return total.value, list(km), list(kl)
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int()
+        mem = C.c_double()
+        self._chk(self.lib.mchip_device_info(self.h, name, 256, C.byref(cu), C.byref(mem)))
+        return name.value.decode(), cu.value, mem.value
