@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- EM iterations/s of the MI355X EM hot path on BASELINE.json's workload.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (default "c3", BASELINE.json configs[2], the configuration north_star's target is quoted on):
+10 000 diploid individuals x 100 000 loci, M_l ~ U{2,3,4} alleles, admixture K = 8, SQUAREM-3 (-s 3), one
+initialisation per GPU.  A "step" is one pass of the hot path as the reference sequences it for -s 3: one
+accelerated_em_step() cycle = 2 EM iterations (E+M, n_iter += 2) + 2 stand-alone log-likelihood passes +
+step size + extrapolation/projection (accel_em.c:35-114), driven by the plain-C host side over the C-ABI.
+value = EM iterations/s summed over ranks (n_iter increments / wall time), inputs resident in HBM.
+
+Multi-GPU: the path shards by independent units (random initialisations, multiclust.c:516-653): rank r fits
+its own initialisation on its own GPU with no data-path collective; one RCCL all-reduce (MAX) picks the best
+log likelihood at the end (inside the timed region).  scaling = "weak".
+
+Also reported on the same JSON line: `roofline` for the dominant kernel (HIP events on the library's own
+stream) and `cpu_baseline` (the CPU oracle, timed on a bounded sample on rank 0 at N = 1 only; the oracle is
+used here only as the baseline, never as the measured path).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TF = 78.6    # vector FP64 peak (spec), for the secondary fraction only
+
+WORKLOADS = {
+    # name: I, L, ploidy, max alleles, K, accel scheme, description
+    "c3": dict(I=10000, L=100000, ploidy=2, maxal=4, K=8, accel=3,
+               desc="10000 diploid x 100000 loci, M_l~U{2,3,4}, admixture K=8, SQUAREM-3 (-s 3)"),
+    "c2": dict(I=2000, L=20000, ploidy=2, maxal=2, K=5, accel=0,
+               desc="2000 diploid x 20000 biallelic loci, admixture K=5, plain EM (-s 0)"),
+    "c1": dict(I=100, L=500, ploidy=2, maxal=2, K=3, accel=0,
+               desc="100 diploid x 500 biallelic loci, admixture K=3, plain EM"),
+    "c5": dict(I=5000, L=50000, ploidy=4, maxal=4, K=8, accel=0,
+               desc="5000 tetraploid x 50000 loci, M_l~U{2,3,4}, admixture K=8, plain EM"),
+}
+
+
+def gen_dataset(I, L, K, ploidy, maxal, seed, device):
+    """SURVEY.md 8d generator on the GPU (torch is plumbing here): P_kl ~ Dirichlet(0.5), Q_i ~ Dirichlet(0.2),
+    z ~ Cat(Q_i) per allele copy, allele ~ Cat(P_z,l).  Returns host arrays (the C-ABI takes host buffers)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    if maxal > 2:
+        ua = torch.randint(2, maxal + 1, (L,), generator=g, device=device)
+    else:
+        ua = torch.full((L,), 2, device=device, dtype=torch.int64)
+    M = int(ua.max())
+    conc = torch.full((K, L, M), 0.5, device=device)
+    P = torch._standard_gamma(conc, generator=g) + 1e-3
+    P = P * (torch.arange(M, device=device)[None, None, :] < ua[None, :, None])
+    P = P / P.sum(dim=2, keepdim=True)
+    cdf = torch.cumsum(P, dim=2).float()
+    Qg = torch._standard_gamma(torch.full((I, K), 0.2, device=device), generator=g) + 1e-6
+    qcdf = torch.cumsum(Qg / Qg.sum(dim=1, keepdim=True), dim=1).float()
+    geno = np.empty((I, L, ploidy), dtype=np.uint8)
+    lidx = torch.arange(L, device=device)[None, :, None]
+    chunk = max(1, int(2.5e8 // (L * ploidy * max(M, K))))
+    for i0 in range(0, I, chunk):
+        i1 = min(I, i0 + chunk)
+        n = i1 - i0
+        u = torch.rand((n, L, ploidy), generator=g, device=device)
+        z = (u[..., None] > qcdf[i0:i1, None, None, :K - 1]).sum(dim=3) if K > 1 else torch.zeros((n, L, ploidy), dtype=torch.int64, device=device)
+        u2 = torch.rand((n, L, ploidy), generator=g, device=device)
+        c = cdf[z, lidx.expand(n, L, ploidy)]                  # (n, L, ploidy, M)
+        a = (u2[..., None] > c[..., :M - 1]).sum(dim=3)
+        a = torch.minimum(a, (ua[None, :, None] - 1))
+        geno[i0:i1] = a.to(torch.uint8).cpu().numpy()
+    return ua.to(torch.int32).cpu().numpy(), geno
+
+
+def algorithmic_bytes(w, T):
+    I, L, p, K = w["I"], w["L"], w["ploidy"], w["K"]
+    g = I * L * p
+    return {
+        "iteration": g + 16 * K * T + 16 * I * K,            # B_it
+        "column_pass": g + 16 * K * T + 8 * I * K,           # genotype + read P, write N-side sums + read Q
+        "individual_pass": g + 8 * K * T + 16 * I * K,       # genotype + read P + read Q, write S-side sums
+        "loglik_pass": g + 8 * K * T + 8 * I * K,
+    }
+
+
+def cpu_baseline(w, ua, geno, accel, budget_s=20.0):
+    """The CPU oracle (oracle/mc_oracle.c, fused order, one host core) on a bounded sample of the same
+    workload: the first L_s loci of every individual, sized for about `budget_s` seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_bind as ob
+    from synth import random_params
+    I, L, p, K = w["I"], w["L"], w["ploidy"], w["K"]
+    per_cell_ns = 12.0 * K                                     # rough: calibrated below
+    iters = 4 if accel else 3
+    passes = iters * (1.6 if accel else 1.0)
+    Ls = int(max(8, min(L, budget_s * 1e9 / (per_cell_ns * I * p * passes))))
+    ua_s = np.ascontiguousarray(ua[:Ls])
+    geno_s = np.ascontiguousarray(geno[:, :Ls, :])
+    lb = ob.lib.mco_lower_bound(1e-8, I, p)
+    q0, p0 = random_params(I, ua_s, K, seed=11, lower_bound=lb)
+    opt = ob.make_options(lower_bound=lb, fused=1, accel_scheme=accel, abs_error=1e-300)
+    mod = ob.Model(ob.Data(I, Ls, p, ua_s, geno_s), opt, K)
+    mod.q(0)[...] = q0
+    mod.p(0)[...] = p0
+    t0 = time.perf_counter()
+    if accel:
+        for _ in range(iters // 2):
+            mod.accelerated_em_step()
+    else:
+        for _ in range(iters):
+            mod.em_step()
+    dt = time.perf_counter() - t0
+    it_s_sample = mod.n_iter / dt
+    return {
+        "value": it_s_sample * Ls / L, "unit": "EM iterations/s", "cores": 1, "kind": "port",
+        "sample": "first %d of %d loci, all %d individuals, %d EM iterations (%s) in %.1f s on one core; "
+                  "scaled by %d/%d (cost is linear in loci)" % (Ls, L, I, mod.n_iter, "SQUAREM-3 cycles" if accel else "plain EM", dt, Ls, L),
+        "sample_value": it_s_sample,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--accel", type=int, default=None, help="override the workload's acceleration scheme (0..6)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from multiclust_amd import hip, host
+    w = dict(WORKLOADS[args.workload])
+    accel = w["accel"] if args.accel is None else args.accel
+    ua, geno = gen_dataset(w["I"], w["L"], w["K"], w["ploidy"], w["maxal"], 20250117 + 3, dev)
+    T = int(ua.sum())
+    torch.cuda.empty_cache()
+
+    fit = host.Fit(ua, geno, w["K"], device=local_rank, admixture=1, accel_scheme=accel, verbosity=1,
+                   abs_error=1e-300)          # never "converges": exactly K timed steps
+    hlib = hip.load()
+    ctx = C.c_void_p(fit.mod.dev)
+    # one initialisation per rank: random allele partition (rnd_init.c:456-482) drawn with a per-rank seed,
+    # first M step on the device (the glibc-stream jump-ahead that gives the serial program's draws is a
+    # "next" row)
+    rng = np.random.default_rng(1234567 + rank)
+    assign = rng.integers(0, w["K"], size=geno.shape, dtype=np.uint8)
+    rc = hlib.mchip_mstep_from_partition(ctx, assign.ctypes.data, 0)
+    if rc:
+        raise SystemExit("mstep_from_partition failed: %s" % hlib.mchip_last_error(ctx).decode())
+    del assign
+
+    iters_per_step = 2 if accel else 1
+
+    def one_step():
+        if accel:
+            fit.accelerated_em_step()
+        else:
+            fit.em_step()
+        if fit.mod.fatal:
+            raise SystemExit("EM stopped with fatal=%d" % fit.mod.fatal)
+
+    for _ in range(args.warmup):
+        one_step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        hlib.mchip_synchronize(ctx)
+
+    barrier()
+    n_iter0 = fit.mod.n_iter
+    hlib.mchip_profile_begin(ctx)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    best = torch.tensor([fit.mod.logL], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(best, op=dist.ReduceOp.MAX)     # the path's one exchange: best log likelihood over units
+    barrier()
+    dt = time.perf_counter() - t0
+    total_ms = C.c_double()
+    km = (C.c_double * hip.PROF_KINDS)()
+    kl = (C.c_int * hip.PROF_KINDS)()
+    hlib.mchip_profile_end(ctx, C.byref(total_ms), km, kl)
+    n_iter = fit.mod.n_iter - n_iter0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    its = torch.tensor([float(n_iter)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(its, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    total_iters = float(its.item())
+
+    if rank == 0:
+        B = algorithmic_bytes(w, T)
+        names = ["column_pass", "individual_pass", "loglik_pass"]
+        avg = [km[x] / kl[x] if kl[x] else 0.0 for x in range(hip.PROF_KINDS)]
+        dom = max(range(2), key=lambda x: avg[x])
+        ach = B[names[dom]] / (avg[dom] * 1e-3) / 1e9 if avg[dom] else 0.0
+        nnz_flops = (5 * w["K"] + 5) * w["I"] * T          # SURVEY.md 8d, dense-over-columns upper bound
+        value = total_iters / dt
+        out = {
+            "metric": "EM iterations/sec, IxLxK admixture",
+            "value": value, "unit": "EM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, w["desc"]), "I": w["I"], "L": w["L"], "T": T,
+                       "ploidy": w["ploidy"], "K": w["K"], "accel_scheme": accel,
+                       "em_iterations_per_step": iters_per_step, "units": "%d initialisation(s), one per GPU" % world,
+                       "best_logL": float(best.item())},
+            "roofline": {
+                "bound": "hbm", "kernel": "k_column_pass" if dom == 0 else "k_individual_pass",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": B[names[dom]], "avg_launch_ms": avg[dom],
+                "kernels_ms": {names[x]: avg[x] for x in range(hip.PROF_KINDS)},
+                "launches": {names[x]: kl[x] for x in range(hip.PROF_KINDS)},
+                "iteration_bytes": B["iteration"],
+                "iteration_hbm_frac": B["iteration"] * (value / world) / 1e9 / HBM_PEAK_GBS,
+                "fp64_valu_frac": nnz_flops * (value / world) / 1e12 / FP64_VALU_PEAK_TF,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget)
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    fit.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

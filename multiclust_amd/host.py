@@ -1,0 +1,165 @@
+"""ctypes view of multiclust_amd/host/mc_host.h (libmulticlust_host.so): the plain-C host side that mirrors
+the reference's em()/em_step()/stop()/accelerated_em_step() over the C-ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import hip
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class McOptions(C.Structure):
+    _fields_ = [("admixture", C.c_int), ("eta_constrained", C.c_int), ("do_projection", C.c_int),
+                ("accel_scheme", C.c_int), ("q", C.c_int), ("n_init_iter", C.c_int), ("max_iter", C.c_int),
+                ("n_seconds", C.c_uint), ("adjust_step", C.c_int), ("verbosity", C.c_int),
+                ("abs_error", C.c_double), ("rel_error", C.c_double), ("lower_bound", C.c_double),
+                ("eta_lower_bound", C.c_double), ("p_lower_bound", C.c_double), ("seed", C.c_uint)]
+
+
+class McData(C.Structure):
+    _fields_ = [("I", C.c_int), ("L", C.c_int), ("ploidy", C.c_int),
+                ("uniquealleles", C.c_void_p), ("geno", C.c_void_p)]
+
+
+class McModel(C.Structure):
+    _fields_ = [("K", C.c_int), ("pindex", C.c_int), ("findex", C.c_int), ("tindex", C.c_int),
+                ("delta_index", C.c_int), ("logL", C.c_double), ("n_iter", C.c_int), ("converged", C.c_int),
+                ("stopped", C.c_int), ("accel_step", C.c_int), ("iter_stop", C.c_int), ("time_stop", C.c_int),
+                ("fatal", C.c_int), ("start", C.c_long), ("seconds_run", C.c_double),
+                ("A", C.c_double * 9), ("Ainv", C.c_double * 9), ("cutu", C.c_double * 3),
+                ("last_emll", C.c_double), ("last_step", C.c_double), ("last_ll", C.c_double),
+                ("last_accepted", C.c_int), ("dev", C.c_void_p), ("owns_dev", C.c_int)]
+
+
+class McRng(C.Structure):
+    _fields_ = [("r", C.c_int32 * 31), ("f", C.c_int), ("b", C.c_int)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    hip.load()      # dependency; raises loudly if the HIP library is missing
+    path = os.path.join(_HERE, "lib", "libmulticlust_host.so")
+    if not os.path.exists(path):
+        raise hip.HipError("%s is missing: run `make`" % path)
+    lib = C.CDLL(path)
+    OP, DP, MP = C.POINTER(McOptions), C.POINTER(McData), C.POINTER(McModel)
+    lib.mc_make_options.argtypes = [OP]
+    lib.mc_synchronize.argtypes = [OP, DP]
+    lib.mc_model_create.argtypes = [C.POINTER(MP), OP, DP, C.c_int, C.c_int]
+    lib.mc_model_free.argtypes = [MP]
+    for fn in ("mc_model_set_p", "mc_model_get_p", "mc_model_set_q", "mc_model_get_q"):
+        getattr(lib, fn).argtypes = [MP, C.c_int, C.c_void_p]
+    lib.mc_model_get_expected_counts.argtypes = [MP, C.c_void_p]
+    lib.mc_initialize_model.argtypes = [OP, DP, MP, C.POINTER(McRng)]
+    lib.mc_reset_model_state.argtypes = [MP]
+    lib.mc_em.argtypes = [OP, DP, MP]
+    lib.mc_em.restype = None
+    lib.mc_em_step.argtypes = [OP, DP, MP]
+    lib.mc_em_e_step.argtypes = [OP, DP, MP]
+    lib.mc_em_e_step.restype = C.c_double
+    lib.mc_em_2_steps.argtypes = [MP, DP, OP]
+    lib.mc_accelerated_em_step.argtypes = [OP, DP, MP]
+    lib.mc_log_likelihood.argtypes = [OP, DP, MP, C.c_int]
+    lib.mc_log_likelihood.restype = C.c_double
+    lib.mc_srand.argtypes = [C.POINTER(McRng), C.c_uint]
+    lib.mc_rand.argtypes = [C.POINTER(McRng)]
+    lib.mc_no_parameters.argtypes = [OP, DP, C.c_int]
+    lib.mc_aic.restype = C.c_double
+    lib.mc_aic.argtypes = [C.c_double, C.c_int]
+    lib.mc_bic.restype = C.c_double
+    lib.mc_bic.argtypes = [C.c_double, C.c_int, C.c_int]
+    _lib = lib
+    return lib
+
+
+class Fit:
+    """options + data + model triple, the argument convention of the reference's EM layer."""
+
+    def __init__(self, ua, geno, K, device=0, **opts):
+        self.lib = load()
+        self.ua = np.ascontiguousarray(ua, dtype=np.int32)
+        self.geno = np.ascontiguousarray(geno, dtype=np.uint8)
+        I, L, p = self.geno.shape
+        self.opt = McOptions()
+        self.lib.mc_make_options(C.byref(self.opt))
+        for k, v in opts.items():
+            setattr(self.opt, k, v)
+        self.dat = McData(I, L, p, self.ua.ctypes.data, self.geno.ctypes.data)
+        if self.lib.mc_synchronize(C.byref(self.opt), C.byref(self.dat)):
+            raise hip.HipError("mc_synchronize failed")
+        self.mp = C.POINTER(McModel)()
+        rc = self.lib.mc_model_create(C.byref(self.mp), C.byref(self.opt), C.byref(self.dat), K, device)
+        if rc:
+            raise hip.HipError("mc_model_create failed with status %d (no GPU => no product path)" % rc)
+        self.K, self.I, self.T = K, I, int(self.ua.sum())
+        self.indiv_q = bool(self.opt.admixture and not self.opt.eta_constrained)
+
+    mod = property(lambda s: s.mp.contents)
+
+    def close(self):
+        if self.mp:
+            self.lib.mc_model_free(self.mp)
+            self.mp = C.POINTER(McModel)()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _a(self):
+        return C.byref(self.opt), C.byref(self.dat), self.mp
+
+    def set_params(self, q, p, slot=0):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        assert not self.lib.mc_model_set_q(self.mp, slot, q.ctypes.data)
+        assert not self.lib.mc_model_set_p(self.mp, slot, p.ctypes.data)
+
+    def get_q(self, slot):
+        q = np.empty((self.I, self.K) if self.indiv_q else (self.K,))
+        assert not self.lib.mc_model_get_q(self.mp, slot, q.ctypes.data)
+        return q
+
+    def get_p(self, slot):
+        p = np.empty((self.K, self.T))
+        assert not self.lib.mc_model_get_p(self.mp, slot, p.ctypes.data)
+        return p
+
+    def expected_counts(self):
+        s = np.empty((self.I, self.K))
+        assert not self.lib.mc_model_get_expected_counts(self.mp, s.ctypes.data)
+        return s
+
+    def reset(self):
+        self.lib.mc_reset_model_state(self.mp)
+
+    def initialize(self, seed):
+        rng = McRng()
+        self.lib.mc_srand(C.byref(rng), seed)
+        rc = self.lib.mc_initialize_model(C.byref(self.opt), C.byref(self.dat), self.mp, C.byref(rng))
+        if rc:
+            raise hip.HipError("mc_initialize_model failed (%d)" % rc)
+        return rng
+
+    def em(self):
+        self.lib.mc_em(*self._a())
+
+    def em_step(self):
+        return self.lib.mc_em_step(*self._a())
+
+    def em_e_step(self):
+        return self.lib.mc_em_e_step(*self._a())
+
+    def accelerated_em_step(self):
+        return self.lib.mc_accelerated_em_step(*self._a())
+
+    def log_likelihood(self, which):
+        return self.lib.mc_log_likelihood(C.byref(self.opt), C.byref(self.dat), self.mp, which)

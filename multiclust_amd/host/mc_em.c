@@ -1,0 +1,445 @@
+/*
+ * mc_em.c -- host control flow of the EM hot path over the C-ABI (see mc_host.h).
+ * Sequencing follows reference em_alg.c:44-233,1072-1211 and accel_em.c:35-551; every array operation
+ * is a call into libmulticlust_hip.so.  No arithmetic on genotype-sized data happens on the host.
+ */
+#include "mc_host.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static const char *accel_abbrev[] = { "EM", "S1", "S2", "S3", "QN" };
+
+/* ------------------------------------------------------------------ libc-compatible rand() */
+void mc_srand(mc_rng *g, unsigned int seed)
+{
+	int32_t word;
+	if (seed == 0) seed = 1;
+	word = (int32_t)seed;
+	g->r[0] = word;
+	for (int i = 1; i < 31; i++) {
+		long hi = word / 127773, lo = word % 127773;
+		word = (int32_t)(16807 * lo - 2836 * hi);
+		if (word < 0) word += 2147483647;
+		g->r[i] = word;
+	}
+	g->f = 3;
+	g->b = 0;
+	for (int i = 0; i < 310; i++) (void)mc_rand(g);
+}
+
+int mc_rand(mc_rng *g)
+{
+	uint32_t v = (uint32_t)g->r[g->f] + (uint32_t)g->r[g->b];
+	g->r[g->f] = (int32_t)v;
+	if (++g->f >= 31) g->f = 0;
+	if (++g->b >= 31) g->b = 0;
+	return (int)(v >> 1);
+}
+
+/* ------------------------------------------------------------------ options */
+void mc_make_options(mc_options *opt)
+{
+	memset(opt, 0, sizeof *opt);
+	opt->seed = 1234567;
+	opt->max_iter = 0;
+	opt->rel_error = 0;
+	opt->abs_error = 1e-4;
+	opt->lower_bound = opt->eta_lower_bound = opt->p_lower_bound = 1e-8;
+	opt->do_projection = 1;
+	opt->q = 1;
+	opt->verbosity = MC_MINIMAL;
+}
+
+int mc_synchronize(mc_options *opt, const mc_data *dat)
+{
+	/* multiclust.c:812-815 */
+	double alt = 1.0 / dat->I / dat->ploidy - 0.5 / dat->I / dat->ploidy;
+	if (alt < opt->lower_bound) opt->lower_bound = alt;
+	opt->eta_lower_bound = opt->lower_bound;
+	opt->p_lower_bound = opt->lower_bound;
+	/* multiclust.c:818-851 */
+	if (opt->accel_scheme >= MC_QN) {
+		opt->adjust_step = 0;
+		opt->q = opt->accel_scheme - MC_SQS3;
+		if (opt->q > MCHIP_MAX_SECANTS) {
+			fprintf(stderr, "ERROR [mc_em.c::mc_synchronize]: Cannot use acceleration methods greater than 6 (QN3) "
+				"without linking to lapack.\n");
+			return 1;
+		}
+	}
+	return 0;
+}
+
+int mc_no_parameters(const mc_options *opt, const mc_data *dat, int K)
+{
+	int n = (!opt->admixture || opt->eta_constrained) ? (K - 1) : dat->I * (K - 1);
+	for (int l = 0; l < dat->L; l++) n += (dat->uniquealleles[l] - 1) * K;
+	return n;
+}
+double mc_aic(double max_logL, int no_parameters) { return -2 * max_logL + 2 * no_parameters; }
+double mc_bic(double max_logL, int no_parameters, int I) { return -2 * max_logL + no_parameters * log((double)I); }
+
+/* ------------------------------------------------------------------ model */
+static int dev_fail(mc_model *mod, int rc, const char *what)
+{
+	if (rc) {
+		fprintf(stderr, "ERROR [mc_em.c::%s]: device call failed (%d): %s\n", what, rc,
+			mod && mod->dev ? mchip_last_error(mod->dev) : "no context");
+		if (mod) { mod->fatal = MC_FATAL_DEVICE; mod->stopped = 1; }
+	}
+	return rc;
+}
+
+void mc_reset_model_state(mc_model *mod)
+{
+	mod->n_iter = 0;
+	mod->logL = -INFINITY;		/* rnd_init.c:59 */
+	mod->converged = 0;
+	mod->stopped = 0;
+	mod->iter_stop = 0;
+	mod->time_stop = 0;
+	mod->accel_step = 0;
+	mod->fatal = 0;
+	mod->pindex = mod->findex = mod->tindex = 0;
+	mod->delta_index = 0;
+	mod->start = clock();
+	mod->seconds_run = 0;
+}
+
+int mc_model_create(mc_model **out, const mc_options *opt, const mc_data *dat, int K, int device)
+{
+	mc_model *mod = calloc(1, sizeof *mod);
+	int rc;
+	*out = NULL;
+	if (!mod) return MCHIP_ERR_ALLOC;
+	mod->K = K;
+	if ((rc = mchip_create(&mod->dev, device))) {
+		fprintf(stderr, "ERROR [mc_em.c::mc_model_create]: cannot create a HIP context on device %d (status %d); "
+			"this build has no CPU path\n", device, rc);
+		free(mod);
+		return rc;
+	}
+	mod->owns_dev = 1;
+	if ((rc = mchip_set_genotypes(mod->dev, dat->I, dat->L, dat->ploidy, dat->uniquealleles, dat->geno)) ||
+	    (rc = mchip_set_model(mod->dev, K, opt->admixture, opt->eta_constrained, opt->do_projection,
+				  opt->eta_lower_bound, opt->p_lower_bound, opt->accel_scheme ? opt->q : 0))) {
+		fprintf(stderr, "ERROR [mc_em.c::mc_model_create]: %s\n", mchip_last_error(mod->dev));
+		mchip_destroy(mod->dev);
+		free(mod);
+		return rc;
+	}
+	mc_reset_model_state(mod);
+	*out = mod;
+	return 0;
+}
+
+void mc_model_free(mc_model *mod)
+{
+	if (!mod) return;
+	if (mod->owns_dev && mod->dev) mchip_destroy(mod->dev);
+	free(mod);
+}
+
+const char *mc_model_error(const mc_model *mod) { return mod && mod->dev ? mchip_last_error(mod->dev) : ""; }
+int mc_model_set_p(mc_model *mod, int slot, const double *p) { return mchip_set_p(mod->dev, slot, p); }
+int mc_model_get_p(mc_model *mod, int slot, double *p) { return mchip_get_p(mod->dev, slot, p); }
+int mc_model_set_q(mc_model *mod, int slot, const double *q) { return mchip_set_q(mod->dev, slot, q); }
+int mc_model_get_q(mc_model *mod, int slot, double *q) { return mchip_get_q(mod->dev, slot, q); }
+int mc_model_get_expected_counts(mc_model *mod, double *sik) { return mchip_get_expected_counts(mod->dev, sik); }
+
+int mc_initialize_model(const mc_options *opt, const mc_data *dat, mc_model *mod, mc_rng *rng)
+{
+	/* rnd_init.c:54-89 reset, then random_initialize_admixture (349-357): one rand() % K per allele copy in
+	 * i, l, a order (456-467), first M step on the device */
+	size_t n = (size_t)dat->I * dat->L * dat->ploidy;
+	uint8_t *assign;
+	int rc;
+	mod->n_iter = 0;
+	mod->logL = -INFINITY;
+	mod->converged = 0;
+	if (opt->accel_scheme) mod->pindex = mod->tindex = mod->findex = 0;
+	if (!opt->admixture) {
+		fprintf(stderr, "ERROR [mc_em.c::mc_initialize_model]: mixture-model initialisation is not built\n");
+		return MCHIP_ERR_UNSUPPORTED;
+	}
+	if (!(assign = malloc(n))) return MCHIP_ERR_ALLOC;
+	for (size_t j = 0; j < n; j++) assign[j] = (uint8_t)(mc_rand(rng) % mod->K);
+	rc = mchip_mstep_from_partition(mod->dev, assign, mod->tindex);
+	free(assign);
+	return dev_fail(mod, rc, "mc_initialize_model");
+}
+
+/* ------------------------------------------------------------------ stopping rules */
+int mc_converged(const mc_options *opt, mc_model *mod, double loglik)
+{
+	/* em_alg.c:163-182 */
+	int stop = 1;
+	double abs_diff = 0, rel_diff = 0;
+	if (opt->abs_error) abs_diff = fabs(loglik - mod->logL);
+	if (opt->rel_error) rel_diff = abs_diff / fabs(mod->logL);
+	if (opt->abs_error && abs_diff > opt->abs_error) stop &= 0;
+	if (opt->rel_error && rel_diff > opt->rel_error) stop &= 0;
+	if (stop) mod->converged = 1;
+	return stop;
+}
+
+static int stop_condition(const mc_options *opt, mc_model *mod, double loglik)
+{
+	/* em_alg.c:145-161 */
+	mod->seconds_run = ((double)clock() - mod->start) / CLOCKS_PER_SEC;
+	if (opt->max_iter && mod->n_iter > opt->max_iter) {
+		mod->iter_stop = 1;
+		return 1;
+	}
+	if (opt->n_seconds && mod->seconds_run > opt->n_seconds) {
+		mod->time_stop = 1;
+		return 1;
+	}
+	return mc_converged(opt, mod, loglik);
+}
+
+int mc_stop(const mc_options *opt, mc_model *mod, double loglik)
+{
+	/* em_alg.c:101-143 */
+	mod->n_iter++;
+	if (isnan(loglik)) {
+		fprintf(stderr, "ERROR [em_alg.c::stop(107)]: nan\n");
+		mod->fatal = MC_FATAL_NAN;
+		mod->stopped = 1;
+		return 1;
+	}
+	mod->stopped = stop_condition(opt, mod, loglik);
+	if (loglik < mod->logL && !mod->stopped) {
+		fprintf(stderr, "ERROR [em_alg.c::stop(116)]: log likelihood decrease (%f < %f; %e)\n",
+			loglik, mod->logL, (loglik - mod->logL) / loglik);
+		mod->fatal = MC_FATAL_DECREASE;
+		mod->stopped = 1;
+		return 1;
+	}
+	if (opt->verbosity > MC_MINIMAL) {
+		fprintf(stderr, "%4d (%s", mod->n_iter,
+			mod->accel_step ? accel_abbrev[opt->accel_scheme < MC_QN ? opt->accel_scheme : MC_QN] : "EM");
+		if (mod->accel_step && opt->accel_scheme > MC_QN) fprintf(stderr, "%d", opt->q);
+		fprintf(stderr, "): %.2f (delta): %.5g\n", loglik, loglik - mod->logL);
+	}
+	mod->accel_step = 0;
+	mod->logL = loglik;
+	return mod->stopped;
+}
+
+/* ------------------------------------------------------------------ EM steps */
+int mc_em_step(const mc_options *opt, const mc_data *dat, mc_model *mod)
+{
+	/* em_alg.c:195-207 */
+	double ll = NAN;
+	(void)dat;
+	if (dev_fail(mod, mchip_em_step(mod->dev, mod->findex, mod->tindex, &ll), "mc_em_step")) return 1;
+	return mc_stop(opt, mod, ll);
+}
+
+double mc_em_e_step(const mc_options *opt, const mc_data *dat, mc_model *mod)
+{
+	/* em_alg.c:219-233: E, M, E; returns the log likelihood after the step */
+	double ll = NAN;
+	(void)opt; (void)dat;
+	if (dev_fail(mod, mchip_em_step(mod->dev, mod->findex, mod->tindex, NULL), "mc_em_e_step")) return NAN;
+	if (dev_fail(mod, mchip_e_step(mod->dev, mod->tindex, &ll), "mc_em_e_step")) return NAN;
+	return ll;
+}
+
+double mc_log_likelihood(const mc_options *opt, const mc_data *dat, mc_model *mod, int which)
+{
+	double ll = NAN;
+	(void)opt; (void)dat;
+	if (dev_fail(mod, mchip_loglik(mod->dev, which, &ll), "mc_log_likelihood")) return NAN;
+	return ll;
+}
+
+int mc_em_2_steps(mc_model *mod, const mc_data *dat, const mc_options *opt)
+{
+	/* em_alg.c:1072-1211 */
+	mod->findex = mod->pindex;
+	mod->tindex = (mod->findex + 1) % 3;
+	for (int j = 0; j < 2; j++) {
+		if (mc_em_step(opt, dat, mod)) return 1;
+		if (dev_fail(mod, mchip_secant(mod->dev, j, mod->delta_index, mod->tindex, mod->findex), "mc_em_2_steps")) return 1;
+		mod->findex = mod->tindex;
+		mod->tindex = (mod->findex + 1) % 3;
+		if (mod->tindex == mod->pindex) mod->tindex = (mod->tindex + 1) % 3;
+	}
+	mod->delta_index = (mod->delta_index + 1) % opt->q;
+	return 0;
+}
+
+double mc_step_size(const mc_options *opt, const mc_data *dat, mc_model *mod)
+{
+	/* accel_em.c:130-243 */
+	double d[3] = { NAN, NAN, NAN }, s;
+	(void)dat;
+	if (dev_fail(mod, mchip_step_dots(mod->dev, mod->delta_index, d), "mc_step_size")) return NAN;
+	const double utu = d[0], utvu = d[1], vutvu = d[2];
+	if (opt->accel_scheme == MC_SQS1) s = utu / utvu;
+	else if (opt->accel_scheme == MC_SQS2) s = utvu / vutvu;
+	else if (opt->accel_scheme == MC_SQS3) {
+		if (sqrt(utu) < 1e-8) return NAN;
+		s = -sqrt(utu / vutvu);
+	} else if (opt->accel_scheme == MC_QN) s = -utu / utvu;
+	else s = -1;
+	if (opt->accel_scheme < MC_QN && s > -1) s = -1;
+	return s;
+}
+
+double mc_accelerated_update(const mc_options *opt, const mc_data *dat, mc_model *mod, double s)
+{
+	/* accel_em.c:422-551 */
+	double ll;
+	mod->delta_index = mod->delta_index ? mod->delta_index - 1 : opt->q - 1;
+	if (dev_fail(mod, mchip_accel_update(mod->dev, mod->tindex, mod->pindex, mod->delta_index, s,
+					     opt->accel_scheme == MC_QN), "mc_accelerated_update")) return NAN;
+	ll = mc_log_likelihood(opt, dat, mod, mod->tindex);
+	mod->delta_index = (mod->delta_index + 1) % opt->q;
+	return ll;
+}
+
+double mc_qn_accelerated_update(const mc_options *opt, const mc_data *dat, mc_model *mod)
+{
+	/* accel_em.c:262-419, q = 2 or 3 */
+	const int q = opt->q;
+	int vindex = mod->delta_index ? mod->delta_index - 1 : q - 1;
+	int uindex = vindex ? vindex - 1 : q - 1;
+	int q1, q2, j, n, nt = 0;
+	int v_index[9];
+	double ca[9], cb[9], det, d2[2];
+	double *A = mod->A, *Ainv = mod->Ainv;
+
+	q1 = mod->delta_index;
+	j = 0;
+	do {
+		q2 = mod->delta_index;
+		n = 0;
+		do {
+			if (dev_fail(mod, mchip_secant_dots(mod->dev, q1, q2, d2), "mc_qn_accelerated_update")) return NAN;
+			mod->cutu[n] = d2[0];
+			A[j * q + n] = d2[0] - d2[1];
+			n++;
+			q2 = (q2 + 1) % q;
+		} while (q2 != mod->delta_index);
+		q1 = (q1 + 1) % q;
+		j++;
+	} while (q1 != mod->delta_index);
+
+	if (q == 1) {
+		Ainv[0] = 1 / A[0];
+	} else if (q == 2) {
+		det = A[0] * A[3] - A[1] * A[2];
+		Ainv[0] = A[3] / det;
+		Ainv[3] = A[0] / det;
+		Ainv[1] = -A[1] / det;
+		Ainv[2] = -A[2] / det;
+	} else {
+		det = A[0] * (A[4] * A[8] - A[5] * A[7])
+			- A[1] * (A[8] * A[3] - A[5] * A[6])
+			+ A[2] * (A[3] * A[7] - A[4] * A[6]);
+		Ainv[0] = (A[4] * A[8] - A[5] * A[7]) / det;
+		Ainv[1] = (A[2] * A[7] - A[1] * A[8]) / det;
+		Ainv[2] = (A[1] * A[5] - A[2] * A[4]) / det;
+		Ainv[3] = (A[5] * A[6] - A[3] * A[8]) / det;
+		Ainv[4] = (A[0] * A[8] - A[2] * A[6]) / det;
+		Ainv[5] = (A[2] * A[3] - A[0] * A[5]) / det;
+		Ainv[6] = (A[3] * A[7] - A[4] * A[6]) / det;
+		Ainv[7] = (A[1] * A[6] - A[0] * A[7]) / det;
+		Ainv[8] = (A[0] * A[4] - A[1] * A[3]) / det;
+	}
+	q1 = mod->delta_index;
+	j = 0;
+	do {
+		n = 0;
+		q2 = mod->delta_index;
+		do {
+			v_index[nt] = q1;
+			ca[nt] = Ainv[j * q + n];
+			cb[nt] = mod->cutu[n];
+			nt++;
+			q2 = (q2 + 1) % q;
+			n++;
+		} while (q2 != mod->delta_index);
+		q1 = (q1 + 1) % q;
+		j++;
+	} while (q1 != mod->delta_index);
+	if (dev_fail(mod, mchip_multisecant_update(mod->dev, mod->tindex, mod->pindex, uindex, nt, v_index, ca, cb),
+		     "mc_qn_accelerated_update")) return NAN;
+	return mc_log_likelihood(opt, dat, mod, mod->tindex);
+}
+
+int mc_accelerated_em_step(const mc_options *opt, const mc_data *dat, mc_model *mod)
+{
+	/* accel_em.c:35-114 */
+	int n_adjust = 0;
+	double emll, ll = 0, s = 0;
+
+	mc_em_2_steps(mod, dat, opt);
+	if (mod->stopped) return 1;
+	emll = mc_log_likelihood(opt, dat, mod, mod->findex);
+	if (mod->fatal) return 1;
+	mod->last_emll = emll; mod->last_step = 0; mod->last_ll = 0; mod->last_accepted = 0;
+	if (opt->accel_scheme <= MC_QN) {
+		s = mc_step_size(opt, dat, mod);
+		if (mod->fatal) return 1;
+		mod->last_step = s;
+		if (isnan(s) || isinf(s)) goto EM_EXIT;
+	}
+	do {
+		if (opt->accel_scheme <= MC_QN)
+			ll = mc_accelerated_update(opt, dat, mod, s);
+		else
+			ll = mc_qn_accelerated_update(opt, dat, mod);
+		if (mod->fatal) return 1;
+		if (opt->adjust_step && ll < emll) {
+			if (opt->verbosity > MC_MINIMAL)
+				fprintf(stderr, "after attempt %d (of %d) of accel ll is %f, EM ll is %f, step is %f\n",
+					n_adjust, opt->adjust_step, ll, emll, s);
+			s = (s - 1) / 2;
+		}
+	} while (n_adjust++ < opt->adjust_step && ll < emll && s < -1);
+	mod->last_step = s; mod->last_ll = ll;
+	if (opt->verbosity > MC_TALKATIVE)
+		fprintf(stderr, "accelerated_em_step (%s): aEM %f %s EM %f (step size: %f)\n",
+			ll > emll ? accel_abbrev[opt->accel_scheme < MC_QN ? opt->accel_scheme : MC_QN] : "EM",
+			ll, ll > emll ? ">" : "<", emll, s);
+	if (ll > emll) {
+		mod->pindex = mod->tindex;
+		mod->accel_step = 1;
+		mod->last_accepted = 1;
+		return 0;
+	}
+EM_EXIT:
+	mod->pindex = mod->findex;
+	return 0;
+}
+
+void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod)
+{
+	/* em_alg.c:44-90 */
+	int stop = 0;
+	if (mod->K == 1) {
+		mc_em_step(opt, dat, mod);
+		if (!mod->fatal) mod->logL = mc_log_likelihood(opt, dat, mod, mod->tindex);
+		return;
+	}
+	while (mod->n_iter < opt->n_init_iter && !stop)
+		stop = mc_em_step(opt, dat, mod);
+	for (int i = 1; i < opt->q; i++) {
+		mc_em_2_steps(mod, dat, opt);
+		mod->pindex = mod->findex;
+	}
+	if (mod->converged || mod->fatal) return;
+	do {
+		if (!opt->accel_scheme)
+			stop = mc_em_step(opt, dat, mod);
+		else
+			stop = mc_accelerated_em_step(opt, dat, mod);
+	} while (!stop);
+}

@@ -1,0 +1,113 @@
+/*
+ * mc_host.h -- plain-C host side of the MI355X EM hot path.
+ *
+ * Mirrors the reference's EM-layer interface (reference multiclust.h:371-388: em, em_step, em_e_step,
+ * em_2_steps, stop, converged, log_likelihood, accelerated_em_step, ...) with an mc_ prefix and the same
+ * (options*, data*, model*) argument convention, the same ring-index / iteration-count / convergence
+ * semantics and the same stderr lines; all array arithmetic goes through the C-ABI in
+ * include/multiclust_hip.h (one mchip_context per model).  Differences that are deliberate:
+ *   - fatal numerics (NaN logL, logL decrease) set model::fatal and stop instead of exit(0) inside the
+ *     library (reference em_alg.c:106-120); the CLI turns fatal into the reference's exit(0).
+ *   - parameters live on the device; mc_model_get_p/q fetch slot copies in the reference's flat order.
+ */
+#ifndef MC_HOST_H
+#define MC_HOST_H
+
+#include <stdint.h>
+#include <time.h>
+#include "multiclust_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* acceleration schemes (reference multiclust.h:125-131; 5, 6 = QN with q = 2, 3, multiclust.c:818-820) */
+enum { MC_NONE = 0, MC_SQS1, MC_SQS2, MC_SQS3, MC_QN };
+/* verbosity (reference message.h:45-53) */
+enum { MC_ABSOLUTE_SILENCE = 0, MC_SILENT, MC_QUIET, MC_MINIMAL, MC_RESTRAINED, MC_TALKATIVE, MC_VERBOSE, MC_DEBUG };
+/* fatal conditions the reference answers with exit(0) */
+enum { MC_FATAL_NONE = 0, MC_FATAL_NAN = 1, MC_FATAL_DECREASE = 2, MC_FATAL_DEVICE = 3 };
+
+typedef struct mc_options {	/* subset of reference struct _options used by the EM layer (multiclust.h:155-215) */
+	int admixture;
+	int eta_constrained;
+	int do_projection;
+	int accel_scheme;
+	int q;			/* number of secant conditions (QN) */
+	int n_init_iter;
+	int max_iter;
+	unsigned int n_seconds;
+	int adjust_step;
+	int verbosity;
+	double abs_error;
+	double rel_error;
+	double lower_bound;
+	double eta_lower_bound;
+	double p_lower_bound;
+	unsigned int seed;
+} mc_options;
+
+typedef struct mc_data {	/* flat form of reference struct _data's genotype fields (multiclust.h:223-237) */
+	int I, L, ploidy;
+	const int32_t *uniquealleles;	/* [L] */
+	const uint8_t *geno;		/* [I][L][ploidy] allele indices, MCHIP_MISSING = 0xFF */
+} mc_data;
+
+typedef struct mc_model {	/* EM-layer state of reference struct _model (multiclust.h:259-360) */
+	int K;
+	int pindex, findex, tindex;
+	int delta_index;
+	double logL;
+	int n_iter, converged, stopped, accel_step, iter_stop, time_stop;
+	int fatal;
+	clock_t start;
+	double seconds_run;
+	double A[9], Ainv[9], cutu[3];
+	double last_emll, last_step, last_ll;	/* diagnostics of the last accelerated cycle */
+	int last_accepted;
+	mchip_context *dev;
+	int owns_dev;
+} mc_model;
+
+/* glibc-compatible rand() stream (TYPE_3 additive feedback): "same seed" means the same draws as the
+ * reference's srand()/rand() (multiclust.c:1592-1596, rnd_init.c:467) on any libc. */
+typedef struct mc_rng { int32_t r[31]; int f, b; } mc_rng;
+void mc_srand(mc_rng *g, unsigned int seed);
+int mc_rand(mc_rng *g);
+
+void mc_make_options(mc_options *opt);				/* defaults of make_options, multiclust.c:902-978 */
+int mc_synchronize(mc_options *opt, const mc_data *dat);	/* lower bounds + q, multiclust.c:812-820 */
+
+/* allocate_model_for_k (multiclust.c:1181): creates the device context on `device`, uploads dat, sizes for K */
+int mc_model_create(mc_model **mod, const mc_options *opt, const mc_data *dat, int K, int device);
+void mc_model_free(mc_model *mod);
+const char *mc_model_error(const mc_model *mod);
+int mc_model_set_p(mc_model *mod, int slot, const double *p);
+int mc_model_get_p(mc_model *mod, int slot, double *p);
+int mc_model_set_q(mc_model *mod, int slot, const double *q);
+int mc_model_get_q(mc_model *mod, int slot, double *q);
+int mc_model_get_expected_counts(mc_model *mod, double *sik);
+
+/* initialize_model (rnd_init.c:54-89) for the admixture model, random allele partition (349-357,456-482) */
+int mc_initialize_model(const mc_options *opt, const mc_data *dat, mc_model *mod, mc_rng *rng);
+void mc_reset_model_state(mc_model *mod);	/* multiclust.c:518-524 + rnd_init.c:58-71 */
+
+void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod);			/* em_alg.c:44 */
+int mc_em_step(const mc_options *opt, const mc_data *dat, mc_model *mod);		/* em_alg.c:195 */
+double mc_em_e_step(const mc_options *opt, const mc_data *dat, mc_model *mod);		/* em_alg.c:219 */
+int mc_em_2_steps(mc_model *mod, const mc_data *dat, const mc_options *opt);		/* em_alg.c:1072 */
+int mc_stop(const mc_options *opt, mc_model *mod, double loglik);			/* em_alg.c:101 */
+int mc_converged(const mc_options *opt, mc_model *mod, double loglik);			/* em_alg.c:163 */
+double mc_log_likelihood(const mc_options *opt, const mc_data *dat, mc_model *mod, int which);	/* log_likelihood.c:56 */
+int mc_accelerated_em_step(const mc_options *opt, const mc_data *dat, mc_model *mod);	/* accel_em.c:35 */
+double mc_step_size(const mc_options *opt, const mc_data *dat, mc_model *mod);		/* accel_em.c:130 */
+double mc_accelerated_update(const mc_options *opt, const mc_data *dat, mc_model *mod, double s);	/* accel_em.c:422 */
+double mc_qn_accelerated_update(const mc_options *opt, const mc_data *dat, mc_model *mod);	/* accel_em.c:262 */
+double mc_aic(double max_logL, int no_parameters);			/* log_likelihood.c:70 */
+double mc_bic(double max_logL, int no_parameters, int I);		/* log_likelihood.c:82 */
+int mc_no_parameters(const mc_options *opt, const mc_data *dat, int K);	/* multiclust.c:1267-1276 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

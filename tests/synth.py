@@ -19,8 +19,10 @@ def make_dataset(I, L, K, ploidy=2, max_alleles=2, seed=0, missing=0.0, chunk=20
     for i0 in range(0, I, chunk):
         i1 = min(I, i0 + chunk)
         n = i1 - i0
-        z = (rng.random((n, L, ploidy)) > qcdf[i0:i1, None, None, :-1].reshape(n, 1, 1, K - 1)).sum(axis=3) if K > 1 \
-            else np.zeros((n, L, ploidy), dtype=np.int64)
+        if K > 1:
+            z = (rng.random((n, L, ploidy))[..., None] > qcdf[i0:i1, None, None, :-1]).sum(axis=3)
+        else:
+            z = np.zeros((n, L, ploidy), dtype=np.int64)
         u = rng.random((n, L, ploidy))
         c = cdf[z, lidx[None, :, None], :]                      # (n, L, ploidy, M)
         a = (u[..., None] > c[..., :-1]).sum(axis=3)

@@ -1,0 +1,132 @@
+"""-m gpu: the plain-C host side (multiclust_amd/host/mc_em.c: mc_em, mc_stop, mc_accelerated_em_step ...)
+driving the HIP path, against the reference's own full runs (golden) -- iteration counts, convergence
+flags, ring index, log likelihood, final iterate, expected counts."""
+import numpy as np
+import pytest
+
+from golden_util import Golden
+from multiclust_amd import host
+
+pytestmark = pytest.mark.gpu
+
+
+def make_fit(g, accel=0, **kw):
+    fit = host.Fit(g.ua, g.geno, g.K, admixture=g.m["admixture"], eta_constrained=g.m["eta_constrained"],
+                   do_projection=g.m["do_projection"], accel_scheme=accel, verbosity=1, **kw)
+    assert fit.opt.lower_bound == g.lower_bound
+    fit.set_params(g.q("q0"), g.p("p0"))
+    return fit
+
+
+@pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "tetra_admix_k3", "missing_admix_k3",
+                                  "multi_admix_k1", "multi_admix_c_k3"])
+def test_em_to_convergence(name):
+    g = Golden(name)
+    fit = make_fit(g)
+    fit.em()
+    m = fit.mod
+    assert m.fatal == 0
+    # the stopping iteration may shift by one when |delta logL| hovers at abs_error
+    assert abs(m.n_iter - g.m["em_run_n_iter"]) <= 1, (m.n_iter, g.m["em_run_n_iter"])
+    assert m.converged == g.m["em_run_converged"]
+    assert abs(m.logL - g.m["em_run_logL"]) <= 2e-4       # both within abs_error=1e-4 of the fixed point
+    if m.n_iter == g.m["em_run_n_iter"]:
+        assert abs(m.logL - g.m["em_run_logL"]) <= 1e-8
+        np.testing.assert_allclose(fit.get_q(m.pindex), g.q("emrun"), rtol=1e-6, atol=1e-10)
+        np.testing.assert_allclose(fit.get_p(m.pindex), g.p("emrun"), rtol=1e-6, atol=1e-10)
+        np.testing.assert_allclose(fit.expected_counts(), g.sik("emrun"), rtol=1e-6, atol=1e-9)
+    fit.close()
+
+
+@pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "multi_admix_k4_s1", "multi_admix_k4_s2",
+                                  "multi_admix_k3_qn1", "tetra_admix_k3", "missing_admix_k3", "multi_admix_c_k3"])
+def test_accelerated_cycles_trace(name):
+    """First cycles of SQUAREM / QN1 against the reference's recorded emll, step size, ll, accept, ring index."""
+    g = Golden(name)
+    fit = make_fit(g, accel=g.m["accel_scheme"])
+    trace = g.f64("accel_trace.f64").reshape(-1, 8)
+    for c in range(min(5, len(trace))):
+        stop = fit.accelerated_em_step()
+        m = fit.mod
+        assert not stop and m.fatal == 0
+        assert abs(m.last_emll - trace[c, 0]) <= 1e-8, c
+        if trace[c, 7]:
+            assert abs(m.last_step - trace[c, 1]) <= 1e-7 * abs(trace[c, 1]), (c, m.last_step, trace[c, 1])
+            assert abs(m.last_ll - trace[c, 2]) <= 1e-7 * max(1.0, abs(trace[c, 2]) * 1e-3), c
+            assert m.last_accepted == trace[c, 3], c
+        assert m.n_iter == trace[c, 4] and m.pindex == trace[c, 6], c
+        assert abs(m.logL - trace[c, 5]) <= 1e-8
+        if c == 0:
+            np.testing.assert_allclose(fit.get_q(m.pindex), g.q("cycle1"), rtol=1e-7, atol=1e-12)
+            np.testing.assert_allclose(fit.get_p(m.pindex), g.p("cycle1"), rtol=1e-7, atol=1e-12)
+    fit.close()
+
+
+@pytest.mark.parametrize("name", ["multi_admix_k3_qn2", "multi_admix_k3_qn3"])
+def test_quasi_newton_q2_q3_first_cycle(name):
+    g = Golden(name)
+    fit = make_fit(g, accel=g.m["accel_scheme"])
+    assert fit.opt.q == g.m["q"]
+    # em_alg.c:69-72: q-1 secant-collecting double steps, then the first accelerated cycle
+    for _ in range(1, fit.opt.q):
+        fit.lib.mc_em_2_steps(fit.mp, fit.dat, fit.opt)
+        fit.mod.pindex = fit.mod.findex
+    trace = g.f64("accel_trace.f64").reshape(-1, 8)
+    stop = fit.accelerated_em_step()
+    m = fit.mod
+    assert not stop and m.fatal == 0
+    assert abs(m.last_emll - trace[0, 0]) <= 1e-8
+    assert abs(m.last_ll - trace[0, 2]) <= 1e-6 * max(1.0, abs(trace[0, 2]))
+    assert m.last_accepted == trace[0, 3]
+    assert m.n_iter == trace[0, 4] and m.pindex == trace[0, 6]
+    np.testing.assert_allclose(fit.get_p(m.pindex), g.p("cycle1"), rtol=1e-6, atol=1e-10)
+    fit.close()
+
+
+@pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "tetra_admix_k3", "missing_admix_k3"])
+def test_accelerated_run_to_convergence(name):
+    """Whole SQUAREM-3 fit.  The accept test ll > emll can flip on near-ties under re-associated sums
+    (SURVEY.md section 7), so the converged fit is compared within the convergence tolerance."""
+    g = Golden(name)
+    fit = make_fit(g, accel=3)
+    fit.em()
+    m = fit.mod
+    assert m.fatal == 0 and m.converged == 1
+    assert abs(m.logL - g.m["accel_run_logL"]) <= 5e-3, (m.logL, g.m["accel_run_logL"], m.n_iter, g.m["accel_run_n_iter"])
+    if m.n_iter == g.m["accel_run_n_iter"]:
+        assert abs(m.logL - g.m["accel_run_logL"]) <= 1e-7
+        assert m.pindex == g.m["accel_run_pindex"]
+        np.testing.assert_allclose(fit.get_q(m.pindex), g.q("accelrun"), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(fit.get_p(m.pindex), g.p("accelrun"), rtol=1e-5, atol=1e-9)
+    fit.close()
+
+
+@pytest.mark.parametrize("name", ["c1_admix_k3", "missing_admix_k3", "tetra_admix_k3"])
+def test_initialize_model_same_seed(name):
+    g = Golden(name)
+    fit = host.Fit(g.ua, g.geno, g.K, admixture=1, verbosity=1)
+    rng = fit.initialize(g.m["seed"])
+    assert fit.lib.mc_rand(rng) == g.m["rand_after_init"]
+    np.testing.assert_allclose(fit.get_q(0), g.q("q0"), rtol=1e-15, atol=0)
+    np.testing.assert_allclose(fit.get_p(0), g.p("p0"), rtol=1e-15, atol=0)
+    assert fit.mod.logL == -np.inf and fit.mod.n_iter == 0
+    fit.close()
+
+
+def test_max_iter_runs_n_plus_one_steps():
+    """-T n executes n+1 iterations (n_iter > max_iter, em_alg.c:150)."""
+    g = Golden("multi_admix_k4")
+    fit = make_fit(g, max_iter=7)
+    fit.em()
+    assert fit.mod.n_iter == 8 and fit.mod.iter_stop == 1 and fit.mod.converged == 0
+    assert abs(fit.mod.logL - g.f64("em_ll.f64")[7]) <= 1e-8
+    fit.close()
+
+
+def test_em_e_step_returns_post_step_loglik():
+    g = Golden("multi_admix_k4")
+    fit = make_fit(g)
+    ll = fit.em_e_step()
+    assert abs(ll - g.f64("em_ll.f64")[1]) <= 1e-8          # logL entering step 2 = logL after step 1
+    np.testing.assert_allclose(fit.expected_counts().sum(), g.I * g.L * g.ploidy, rtol=1e-12)
+    fit.close()
