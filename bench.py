@@ -98,7 +98,7 @@ def cpu_baseline(w, ua, geno, accel, budget_s=20.0):
     import oracle_bind as ob
     from synth import random_params
     I, L, p, K = w["I"], w["L"], w["ploidy"], w["K"]
-    per_cell_ns = 12.0 * K                                     # rough: calibrated below
+    per_cell_ns = 2.2 * K                                      # measured on the build container's Xeon
     iters = 4 if accel else 3
     passes = iters * (1.6 if accel else 1.0)
     Ls = int(max(8, min(L, budget_s * 1e9 / (per_cell_ns * I * p * passes))))
