@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/...) into the small summaries committed under profiles/.
+
+  python scripts/summarize_profile.py <tag> <kernel-stats-dir> [<pmc-fetch-dir> <pmc-write-dir>]
+
+Writes profiles/<tag>_kernel_stats.csv (library kernels only, from `rocprofv3 --kernel-trace --stats`) and
+profiles/<tag>_traffic.json (per kernel: FETCH_SIZE / WRITE_SIZE averaged per launch, from two separate --pmc
+passes, corrected as MI355X_MICROARCH.md section HBM prescribes: both counters are in KiB; on gfx950 FETCH_SIZE
+reports half the bytes of a wide coalesced read stream, so it is doubled)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    return n.split("(")[0]
+
+
+def ours(name):
+    return "at::" not in name and "rocclr" not in name and ("k_" in name)
+
+
+def main():
+    tag, stats_dir = sys.argv[1], sys.argv[2]
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    f = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(f)) if ours(r["Name"])]
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    out = os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv")
+    with open(out, "w") as g:
+        g.write("kernel,calls,total_ms,avg_ms,min_ms,max_ms,share_of_library_time\n")
+        for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+            g.write("%s,%s,%.3f,%.4f,%.4f,%.4f,%.3f\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                       float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6,
+                                                       float(r["MaxNs"]) / 1e6, float(r["TotalDurationNs"]) / tot))
+    print("wrote", out)
+    if len(sys.argv) >= 5:
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for d in sys.argv[3:5]:
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if ours(r["Kernel_Name"]):
+                        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        res = {}
+        for k, c in agg.items():
+            fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) if c.get("FETCH_SIZE") else None
+            write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) if c.get("WRITE_SIZE") else None
+            res[k] = {
+                "launches_sampled": len(c.get("FETCH_SIZE", [])), "FETCH_SIZE_KiB_per_launch": fetch,
+                "WRITE_SIZE_KiB_per_launch": write,
+                "hbm_bytes_per_launch_corrected": (2 * fetch * 1024 if fetch is not None else 0) + (write * 1024 if write is not None else 0),
+            }
+        out = os.path.join(ROOT, "profiles", tag + "_traffic.json")
+        json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+        print("wrote", out)
+
+
+if __name__ == "__main__":
+    main()
