@@ -49,7 +49,7 @@ struct mchip_context {
 	double *d_sik;			/* [I][K] expected counts / vik */
 	double *d_stage;		/* K*T staging for the [K][T] <-> [T][K] transposes */
 	/* workspaces */
-	int ichunk, n_ichunks, lchunk, n_lchunks, n_llpart, flush_every;
+	int ichunk, n_ichunks, lchunk, n_lchunks, n_llpart, n_ll_col, n_ll_ind, flush_blocks, sparse;
 	double *d_Apart, *d_Spart, *d_llpart, *d_scalars;	/* d_scalars: [0]=logL, [1..3]=dots, [4..]=eta sums */
 	double *d_redpart;		/* block partials of the dot products / column sums */
 	uint8_t *d_flags;		/* michelot "fixed" flags for loci with more than 64 alleles */
@@ -349,9 +349,10 @@ static mchip_pass_args pass_args(mchip_context *ctx, int slot)
 	a.ua = ctx->d_ua; a.toff = ctx->d_toff; a.col_locus = ctx->d_col_locus; a.col_allele = ctx->d_col_allele;
 	a.P = ctx->d_p[slot]; a.Q = ctx->d_q[slot]; a.qstride = ctx->qstride;
 	a.ichunk = ctx->ichunk; a.n_ichunks = ctx->n_ichunks; a.Apart = ctx->d_Apart; a.llpart = ctx->d_llpart;
-	a.flush_every = ctx->flush_every;
+	a.flush_blocks = ctx->flush_blocks;
 	a.lchunk = ctx->lchunk; a.n_lchunks = ctx->n_lchunks; a.Spart = ctx->d_Spart;
 	a.asA = ctx->d_asA; a.asS = ctx->d_asS;
+	a.sparse = ctx->sparse; a.tile_cols = 8 * ctx->max_M;
 	return a;
 }
 
@@ -547,7 +548,10 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	if (want > lblocks) want = lblocks;
 	ctx->lchunk = ((lblocks + want - 1) / want) * 8;
 	ctx->n_lchunks = (ctx->L + ctx->lchunk - 1) / ctx->lchunk;
-	ctx->n_llpart = col_tiles * ctx->n_ichunks;
+	ctx->n_ll_col = col_tiles * ctx->n_ichunks;
+	ctx->n_ll_ind = ind_tiles * ctx->n_lchunks;
+	ctx->sparse = (ctx->max_M <= MCHIP_SPARSE_MAX_M) && !getenv("MCHIP_FORCE_DENSE");
+	ctx->n_llpart = ctx->n_ll_col > ctx->n_ll_ind ? ctx->n_ll_col : ctx->n_ll_ind;
 	HIPCHK(hipMalloc((void **)&ctx->d_Apart, (size_t)ctx->n_ichunks * KT * sizeof(double)));
 	HIPCHK(hipMalloc((void **)&ctx->d_Spart, (size_t)ctx->n_lchunks * ctx->I * K * sizeof(double)));
 	HIPCHK(hipMalloc((void **)&ctx->d_llpart, (size_t)ctx->n_llpart * sizeof(double)));
@@ -555,17 +559,19 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	if (ctx->max_M > 64) {
 		HIPCHK(hipMalloc((void **)&ctx->d_flags, KT));
 	}
-	/* log-product flush interval: with every parameter >= its lower bound, t = sum_k q_k p_k >= p_lb / K, so
-	 * `budget` multiplications keep a product that starts above 1e-100 above 1e-300. */
-	double tmin = p_lb / K;
-	int every = 1;
-	if (do_projection && tmin > 0 && tmin < 1) {
-		double mults = floor(200.0 / -log10(tmin));
-		every = (int)(mults / ctx->ploidy);
-		if (every < 1) every = 1;
-		if (every > 1 << 20) every = 1 << 20;
+	/* log-product check interval: with every parameter >= its lower bound, t = sum_k q_k p_k >= p_lb / K, so
+	 * floor(200 / -log10(t_min)) multiplications keep a product that starts above 1e-100 above 1e-300
+	 * (DESIGN.md section 4).  A block of 8 individuals multiplies 8*ploidy times. */
+	{
+		const double tmin = p_lb / K;
+		int blocks = 0;
+		if (do_projection && tmin > 0 && tmin < 1) {
+			const double mults = floor(200.0 / -log10(tmin));
+			blocks = (int)(mults / (8.0 * ctx->ploidy));
+			if (blocks > 1 << 16) blocks = 1 << 16;
+		}
+		ctx->flush_blocks = blocks;
 	}
-	ctx->flush_every = every;
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	return MCHIP_OK;
 }
@@ -654,13 +660,16 @@ static int finalize_shared_eta(mchip_context *ctx, int to)
 static int run_estep(mchip_context *ctx, int from, int to, int do_mstep)
 {
 	mchip_pass_args a = pass_args(ctx, from);
-	prof_mark(ctx, MCHIP_KERN_ACCUM_P, true);
-	if (do_mstep) ctx->kt->accum_p(a, ctx->stream); else ctx->kt->loglik(a, ctx->stream);
-	prof_mark(ctx, MCHIP_KERN_ACCUM_P, false);
+	if (do_mstep || !ctx->sparse) {
+		prof_mark(ctx, MCHIP_KERN_ACCUM_P, true);
+		if (do_mstep) ctx->kt->accum_p(a, ctx->stream); else ctx->kt->loglik(a, ctx->stream);
+		prof_mark(ctx, MCHIP_KERN_ACCUM_P, false);
+	}
 	prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
 	ctx->kt->accum_q(a, ctx->stream);
 	prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
-	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_llpart, ctx->d_scalars);
+	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart,
+			   ctx->sparse ? ctx->n_ll_ind : ctx->n_ll_col, ctx->d_scalars);
 	const int indiv = ctx->qstride != 0;
 	ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[from], ctx->qstride,
 			    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, ctx->stream);
@@ -716,7 +725,8 @@ int mchip_loglik(mchip_context *ctx, int slot, double *loglik)
 	prof_mark(ctx, MCHIP_KERN_LOGLIK, true);
 	ctx->kt->loglik(a, ctx->stream);
 	prof_mark(ctx, MCHIP_KERN_LOGLIK, false);
-	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_llpart, ctx->d_scalars + 1);
+	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart,
+			   ctx->sparse ? ctx->n_ll_ind : ctx->n_ll_col, ctx->d_scalars + 1);
 	HIPCHK(hipGetLastError());
 	if (loglik) return fetch_scalars(ctx, 1, 1, loglik);
 	return MCHIP_OK;

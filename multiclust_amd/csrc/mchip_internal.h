@@ -20,6 +20,7 @@
 #include "multiclust_hip.h"
 
 #define MCHIP_BLOCK 256
+#define MCHIP_SPARSE_MAX_M 32	/* sparse individual pass is used when no locus has more alleles than this */
 
 enum { MCHIP_KERN_ACCUM_P = 0, MCHIP_KERN_ACCUM_Q = 1, MCHIP_KERN_LOGLIK = 2, MCHIP_KERN_COUNT = 3 };
 
@@ -36,10 +37,13 @@ struct mchip_pass_args {
 	int ichunk, n_ichunks;	/* individuals per chunk (multiple of 8) */
 	double *Apart;		/* [n_ichunks][T][K] sum_i q_ik r_ic over the chunk */
 	double *llpart;		/* [gridDim.x*gridDim.y] block partial log-likelihoods */
-	int flush_every;	/* individuals between log-product flushes */
+	int flush_blocks;	/* blocks of 8 individuals between log-product checks; 0 = check after every individual */
 	/* individual pass (lane = individual, loop over a chunk of loci) */
 	int lchunk, n_lchunks;	/* loci per chunk (multiple of 8) */
 	double *Spart;		/* [n_lchunks][I][K] sum_c P_kc r_ic over the chunk */
+	/* sparse individual pass: P rows of 8 loci staged in LDS */
+	int sparse;		/* 1: sparse individual pass + N-only column pass; 0: dense pair */
+	int tile_cols;		/* LDS tile capacity in allele columns (8 * max alleles per locus) */
 	/* hard-partition first M step */
 	const uint8_t *asA, *asS;	/* assignment bytes in the gtA / gtS layouts */
 };

@@ -56,11 +56,21 @@ template <> struct geno_group<2> {
 		return (int)((w & 0xFFu) == m) + (int)((w >> 8) == m);
 	}
 	__device__ __forceinline__ unsigned copy(int j, int a, int) const { return (field(j) >> (8 * a)) & 0xFFu; }
+	/* entries 4h..4h+3 moved to positions 0..3 (h wave-uniform) */
+	__device__ __forceinline__ geno_group<2> half(int h) const
+	{
+		geno_group<2> r;
+		r.g.x = h ? g.z : g.x;
+		r.g.y = h ? g.w : g.y;
+		r.g.z = 0xFFFFFFFFu;
+		r.g.w = 0xFFFFFFFFu;
+		return r;
+	}
 };
 
 template <> struct geno_group<0> {	/* any ploidy: byte loads */
 	const uint8_t *p;
-	__device__ __forceinline__ void load(const uint8_t *base, size_t group, int pl) { p = base + group * 8 * (size_t)pl; }
+	__device__ __forceinline__ void load(const uint8_t *base, size_t group, int pl) { p = base + group * 8 * (size_t)pl; stride_pl = pl; }
 	__device__ __forceinline__ int count(int j, unsigned m, int pl) const
 	{
 		int n = 0;
@@ -68,14 +78,22 @@ template <> struct geno_group<0> {	/* any ploidy: byte loads */
 		return n;
 	}
 	__device__ __forceinline__ unsigned copy(int j, int a, int pl) const { return p[j * pl + a]; }
+	__device__ __forceinline__ geno_group<0> half(int h) const
+	{
+		geno_group<0> r;
+		r.p = p + h * 4 * stride_pl;
+		r.stride_pl = stride_pl;
+		return r;
+	}
+	int stride_pl;
 };
 
-__device__ __forceinline__ double block_sum_256(double v, double *red)
+template <int NT> __device__ __forceinline__ double block_sum(double v, double *red)
 {
 	const int tid = threadIdx.x;
 	red[tid] = v;
 	__syncthreads();
-	for (int s = 128; s > 0; s >>= 1) {
+	for (int s = NT / 2; s > 0; s >>= 1) {
 		if (tid < s) red[tid] += red[tid + s];
 		__syncthreads();
 	}
@@ -83,7 +101,10 @@ __device__ __forceinline__ double block_sum_256(double v, double *red)
 }
 
 /* ---------------------------------------------------------------- column pass */
-template <int PL, bool ACCUM>
+/* SAFE = false: the log-product is checked once per `flush_blocks` blocks of 8 individuals (host guarantees that
+ * 8*ploidy*flush_blocks multiplications cannot underflow a product that starts above 1e-100);
+ * SAFE = true: checked after every individual (tiny lower bounds, projection disabled, high ploidy). */
+template <int PL, bool ACCUM, bool SAFE, bool LL>
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_pass(mchip_pass_args a)
 {
 	__shared__ double red[MCHIP_BLOCK];
@@ -102,49 +123,71 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_pass(mchip_pass_args a)
 	}
 	const int i0 = blockIdx.y * a.ichunk;
 	const int i1 = min(a.I, i0 + a.ichunk);
+	const int ib_end = (i1 + 7) >> 3;
 	double ll = 0.0, prod = 1.0;
-	int cnt = 0;
+	int blk = 0;
 
-	for (int ib = i0 >> 3; ib < ((i1 + 7) >> 3); ib++) {
-		geno_group<PL> g;
-		g.load(a.gtA, (size_t)ib * a.L + l, pl);
+	geno_group<PL> g, gn;
+	g.load(a.gtA, (size_t)(i0 >> 3) * a.L + l, pl);
+	for (int ib = i0 >> 3; ib < ib_end; ib++) {
+		/* software prefetch of the next group (clamped: the last iteration re-reads its own group) */
+		gn.load(a.gtA, (size_t)min(ib + 1, ib_end - 1) * a.L + l, pl);
+		/* two halves of four individuals: four q rows (4*2K SGPRs) in flight at a time; unrolling all
+		 * eight makes hipcc hoist eight s_load_dwordx16 and spill SGPRs through v_writelane */
+#pragma unroll 1
+		for (int h = 0; h < 2; h++) {
+			const geno_group<PL> gh = g.half(h);
 #pragma unroll
-		for (int j = 0; j < 8; j++) {
-			const int i = min(ib * 8 + j, a.I - 1);	/* padded individuals carry 0xFF bytes: n = 0 */
-			const double *__restrict__ q = a.Q + (size_t)i * a.qstride;	/* wave-uniform: s_load */
-			const int n = g.count(j, m, pl);
-			double t = q[0] * p[0];
+			for (int j = 0; j < 4; j++) {
+				const int i = min(ib * 8 + h * 4 + j, a.I - 1);	/* padded individuals carry 0xFF bytes: n = 0 */
+				const double *__restrict__ q = a.Q + (size_t)i * a.qstride;	/* wave-uniform: s_load */
+				const int n = gh.count(j, m, pl);
+				double t = q[0] * p[0];
 #pragma unroll
-			for (int k = 1; k < K; k++) t = __builtin_fma(q[k], p[k], t);
-			if (ACCUM) {
-				const double r = (double)n * rcp_full(t);
+				for (int k = 1; k < K; k++) t = __builtin_fma(q[k], p[k], t);
+				if (ACCUM) {
+					const double r = (double)n * rcp_full(t);
 #pragma unroll
-				for (int k = 0; k < K; k++) acc[k] = __builtin_fma(q[k], r, acc[k]);
+					for (int k = 0; k < K; k++) acc[k] = __builtin_fma(q[k], r, acc[k]);
+				}
+				/* n log t as log of a product: t^n */
+				if (LL) {
+					if (PL == 2) {
+						prod *= (n >= 1) ? t : 1.0;
+						prod *= (n >= 2) ? t : 1.0;
+					} else {
+						for (int b = 1; b <= pl; b++) prod *= (n >= b) ? t : 1.0;
+					}
+				}
+				if (LL && SAFE) {
+					if (prod < 1e-100) {
+						ll += log(prod);
+						prod = 1.0;
+					}
+				}
 			}
-			/* n log t as log of a product: t^n */
-			if (PL == 2) {
-				prod *= (n >= 1) ? t : 1.0;
-				prod *= (n >= 2) ? t : 1.0;
-			} else {
-				for (int b = 1; b <= pl; b++) prod *= (n >= b) ? t : 1.0;
-			}
-			if (++cnt >= a.flush_every) {
-				cnt = 0;
+		}
+		if (LL && !SAFE) {
+			if (++blk >= a.flush_blocks) {
+				blk = 0;
 				if (prod < 1e-100) {
 					ll += log(prod);
 					prod = 1.0;
 				}
 			}
 		}
+		g = gn;
 	}
-	ll += log(prod);
 	if (ACCUM && valid) {
 		double *out = a.Apart + ((size_t)blockIdx.y * a.T + c) * K;
 #pragma unroll
 		for (int k = 0; k < K; k++) out[k] = acc[k];
 	}
-	const double tot = block_sum_256(ll, red);
-	if (threadIdx.x == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+	if (LL) {
+		ll += log(prod);
+		const double tot = block_sum<MCHIP_BLOCK>(ll, red);
+		if (threadIdx.x == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+	}
 }
 
 /* ---------------------------------------------------------------- individual pass */
@@ -165,19 +208,31 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
 	}
 	const int l0 = blockIdx.y * a.lchunk;
 	const int l1 = min(a.L, l0 + a.lchunk);
-	for (int lb = l0 >> 3; lb < ((l1 + 7) >> 3); lb++) {
-		geno_group<PL> g;
-		g.load(a.gtS, (size_t)lb * a.I + i, pl);
+	const int lb_end = (l1 + 7) >> 3;
+	geno_group<PL> g, gn;
+	g.load(a.gtS, (size_t)(l0 >> 3) * a.I + i, pl);
+	for (int lb = l0 >> 3; lb < lb_end; lb++) {
+		gn.load(a.gtS, (size_t)min(lb + 1, lb_end - 1) * a.I + i, pl);
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
 			const int l = lb * 8 + j;
 			if (l >= l1) break;			/* wave-uniform */
 			const int c0 = a.toff[l];
 			const int M = a.ua[l];
+			/* columns of one locus: P rows are contiguous ([T][K]); the next column's row is requested
+			 * (scalar loads) before this column's arithmetic so its latency hides under it */
+			double pn[K];
+#pragma unroll
+			for (int k = 0; k < K; k++) pn[k] = a.P[(size_t)c0 * K + k];
 			for (int m = 0; m < M; m++) {
+				double pc[K];
+#pragma unroll
+				for (int k = 0; k < K; k++) pc[k] = pn[k];
+				const int cn = min(c0 + m + 1, a.T - 1);
+#pragma unroll
+				for (int k = 0; k < K; k++) pn[k] = a.P[(size_t)cn * K + k];
 				const int n = active ? g.count(j, (unsigned)m, pl) : 0;
 				if (__ballot(n > 0) == 0ull) continue;	/* nobody in this wave carries allele m */
-				const double *__restrict__ pc = a.P + (size_t)(c0 + m) * K;	/* wave-uniform: s_load */
 				double t = q[0] * pc[0];
 #pragma unroll
 				for (int k = 1; k < K; k++) t = __builtin_fma(q[k], pc[k], t);
@@ -186,12 +241,127 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
 				for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[k], r, acc[k]);
 			}
 		}
+		g = gn;
 	}
 	if (active) {
 		double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
 #pragma unroll
 		for (int k = 0; k < K; k++) out[k] = acc[k];
 	}
+}
+
+/* ---------------------------------------------------------------- individual pass, sparse form
+ * lane = individual; only the alleles the individual carries are visited: one term per allele copy
+ * (a homozygote contributes its allele twice, which is the reference's n = 2 cell: same t, r and t^2).
+ * The P rows of the current block of 8 loci are staged in LDS (double-buffered) and gathered per lane with
+ * ds_read_b128; rows of one locus are consecutive, so lanes on different alleles hit different bank groups.
+ * Produces the S-side sums and the log likelihood (one multiply per copy, no selects).  ACCUM = false is the
+ * stand-alone log-likelihood pass (logL_admixture, log_likelihood.c:96-147). */
+constexpr int KP = (K + 1) & ~1;	/* LDS row stride in doubles: rows stay 16-byte aligned */
+
+template <int PL, bool ACCUM, bool SAFE>
+__global__ __launch_bounds__(QBLOCK) void k_individual_sparse(mchip_pass_args a)
+{
+	extern __shared__ __attribute__((aligned(16))) double lds[];	/* [2][tile_cols][KP] then [QBLOCK] reduction scratch */
+	double *red = lds + 2 * (size_t)a.tile_cols * KP;
+	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
+	const bool active = i_raw < a.I;
+	const int i = active ? i_raw : a.I - 1;
+	const int pl = PL ? PL : a.ploidy;
+	double q[K], acc[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+		q[k] = a.Q[(size_t)i * a.qstride + k];
+		acc[k] = 0.0;
+	}
+	const int l0 = blockIdx.y * a.lchunk;
+	const int l1 = min(a.L, l0 + a.lchunk);
+	const int lb0 = l0 >> 3, lb_end = (l1 + 7) >> 3;
+	double ll = 0.0, prod = 1.0;
+	int blk = 0;
+
+	/* stage the first tile */
+	{
+		const int c_lo = a.toff[lb0 * 8], c_hi = a.toff[min(lb0 * 8 + 8, a.L)];
+		const int nel = (c_hi - c_lo) * K;
+		for (int x = threadIdx.x; x < nel; x += QBLOCK)
+			lds[(x / K) * KP + (x % K)] = a.P[(size_t)c_lo * K + x];
+	}
+	geno_group<PL> g, gn;
+	g.load(a.gtS, (size_t)lb0 * a.I + i, pl);
+	__syncthreads();
+	for (int lb = lb0; lb < lb_end; lb++) {
+		const int buf = (lb - lb0) & 1;
+		const double *tile = lds + (size_t)buf * a.tile_cols * KP;
+		const int c_lo = a.toff[lb * 8];
+		/* prefetch the next tile into the other buffer and the next genotype group into registers */
+		if (lb + 1 < lb_end) {
+			const int n_lo = a.toff[(lb + 1) * 8], n_hi = a.toff[min((lb + 1) * 8 + 8, a.L)];
+			const int nel = (n_hi - n_lo) * K;
+			double *dst = lds + (size_t)(buf ^ 1) * a.tile_cols * KP;
+			for (int x = threadIdx.x; x < nel; x += QBLOCK)
+				dst[(x / K) * KP + (x % K)] = a.P[(size_t)n_lo * K + x];
+		}
+		gn.load(a.gtS, (size_t)min(lb + 1, lb_end - 1) * a.I + i, pl);
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const int l = lb * 8 + j;
+			if (l >= l1) break;			/* wave-uniform */
+			const int base = a.toff[l] - c_lo;
+#pragma unroll
+			for (int b = 0; b < (PL ? PL : 1); b++) {
+				for (int bb = 0; bb < (PL ? 1 : pl); bb++) {	/* generic ploidy: runtime loop over copies */
+					const unsigned mraw = g.copy(j, PL ? b : bb, pl);
+					const bool miss = (mraw == MCHIP_MISSING) || !active;
+					const unsigned mm = miss ? 0u : mraw;
+					/* 16-byte LDS reads (ds_read_b128): twice the bytes per LDS cycle of ds_read2_b64 */
+					const double2 *pr = reinterpret_cast<const double2 *>(tile + (size_t)(base + (int)mm) * KP);
+					double pc[KP];
+#pragma unroll
+					for (int k = 0; k < KP / 2; k++) {
+						const double2 v = pr[k];
+						pc[2 * k] = v.x;
+						pc[2 * k + 1] = v.y;
+					}
+					double t = q[0] * pc[0];
+#pragma unroll
+					for (int k = 1; k < K; k++) t = __builtin_fma(q[k], pc[k], t);
+					if (ACCUM) {
+						const double rc = rcp_full(t);
+						const double r = miss ? 0.0 : rc;
+#pragma unroll
+						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[k], r, acc[k]);
+					}
+					prod *= miss ? 1.0 : t;
+					if (SAFE) {
+						if (prod < 1e-100) {
+							ll += log(prod);
+							prod = 1.0;
+						}
+					}
+				}
+			}
+		}
+		if (!SAFE) {
+			if (++blk >= a.flush_blocks) {
+				blk = 0;
+				if (prod < 1e-100) {
+					ll += log(prod);
+					prod = 1.0;
+				}
+			}
+		}
+		g = gn;
+		__syncthreads();	/* next tile is complete and this one may be overwritten */
+	}
+	ll += log(prod);
+	if (ACCUM && active) {
+		double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
+#pragma unroll
+		for (int k = 0; k < K; k++) out[k] = acc[k];
+	}
+	const double tot = block_sum<QBLOCK>(active ? ll : 0.0, red);
+	if (threadIdx.x == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }
 
 /* ---------------------------------------------------------------- hard partition (first M step)
@@ -340,18 +510,38 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_project_q(int nrows, double *Q,
 inline dim3 column_grid(const mchip_pass_args &a) { return dim3((a.T + MCHIP_BLOCK - 1) / MCHIP_BLOCK, a.n_ichunks); }
 inline dim3 indiv_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK - 1) / QBLOCK, a.n_lchunks); }
 
+/* a.sparse: the column pass only accumulates the N-side sums; S-side sums and logL come from the sparse
+ * individual pass.  Otherwise (loci with more alleles than the LDS tile is sized for) the dense pair is used:
+ * the column pass also produces logL and the individual pass loops over every allele of every locus. */
 void launch_accum_p(const mchip_pass_args &a, hipStream_t s)
 {
-	if (a.ploidy == 2) hipLaunchKernelGGL((k_column_pass<2, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
-	else hipLaunchKernelGGL((k_column_pass<0, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+	if (a.sparse) {
+		if (a.ploidy == 2) hipLaunchKernelGGL((k_column_pass<2, true, false, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+		else hipLaunchKernelGGL((k_column_pass<0, true, false, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+		return;
+	}
+	if (a.ploidy == 2 && a.flush_blocks >= 1) hipLaunchKernelGGL((k_column_pass<2, true, false, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+	else if (a.ploidy == 2) hipLaunchKernelGGL((k_column_pass<2, true, true, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+	else hipLaunchKernelGGL((k_column_pass<0, true, true, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+}
+inline size_t sparse_lds_bytes(const mchip_pass_args &a) { return (2 * (size_t)a.tile_cols * KP + QBLOCK) * sizeof(double); }
+template <bool ACCUM> void launch_sparse(const mchip_pass_args &a, hipStream_t s)
+{
+	const size_t lds = sparse_lds_bytes(a);
+	if (a.ploidy == 2 && a.flush_blocks >= 1) hipLaunchKernelGGL((k_individual_sparse<2, ACCUM, false>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
+	else if (a.ploidy == 2) hipLaunchKernelGGL((k_individual_sparse<2, ACCUM, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
+	else hipLaunchKernelGGL((k_individual_sparse<0, ACCUM, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
 }
 void launch_loglik(const mchip_pass_args &a, hipStream_t s)
 {
-	if (a.ploidy == 2) hipLaunchKernelGGL((k_column_pass<2, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
-	else hipLaunchKernelGGL((k_column_pass<0, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+	if (a.sparse) { launch_sparse<false>(a, s); return; }
+	if (a.ploidy == 2 && a.flush_blocks >= 1) hipLaunchKernelGGL((k_column_pass<2, false, false, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+	else if (a.ploidy == 2) hipLaunchKernelGGL((k_column_pass<2, false, true, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+	else hipLaunchKernelGGL((k_column_pass<0, false, true, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
 }
 void launch_accum_q(const mchip_pass_args &a, hipStream_t s)
 {
+	if (a.sparse) { launch_sparse<true>(a, s); return; }
 	if (a.ploidy == 2) hipLaunchKernelGGL((k_individual_pass<2>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
 	else hipLaunchKernelGGL((k_individual_pass<0>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
 }

