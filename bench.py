@@ -234,7 +234,7 @@ def main():
                        "em_iterations_per_step": iters_per_step, "units": "%d initialisation(s), one per GPU" % world,
                        "best_logL": float(best.item())},
             "roofline": {
-                "bound": "hbm", "kernel": "k_column_pass" if dom == 0 else "k_individual_pass",
+                "bound": "hbm", "kernel": "k_column_pass" if dom == 0 else "k_individual_sparse",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": B[names[dom]], "avg_launch_ms": avg[dom],
                 "kernels_ms": {names[x]: avg[x] for x in range(hip.PROF_KINDS)},

@@ -48,6 +48,7 @@ struct mchip_context {
 	double *d_up[MCHIP_MAX_SECANTS], *d_vp[MCHIP_MAX_SECANTS], *d_uq[MCHIP_MAX_SECANTS], *d_vq[MCHIP_MAX_SECANTS];
 	double *d_sik;			/* [I][K] expected counts / vik */
 	double *d_stage;		/* K*T staging for the [K][T] <-> [T][K] transposes */
+	double *d_logp;			/* mixture model: log P table [T][K] */
 	/* workspaces */
 	int ichunk, n_ichunks, lchunk, n_lchunks, n_llpart, n_ll_col, n_ll_ind, flush_blocks, sparse;
 	double *d_Apart, *d_Spart, *d_llpart, *d_scalars;	/* d_scalars: [0]=logL, [1..3]=dots, [4..]=eta sums */
@@ -239,6 +240,16 @@ __global__ void k_normalize_row(const double *__restrict__ sums, int K, double *
 	for (int k = 0; k < K; k++) eta[k] = sums[k] / temp;
 }
 
+/* mixture model: log P table; the E step skips p == 0 cells (em_alg.c:797-804), logL_mixture does not
+ * (log_likelihood.c:197-200) */
+__global__ void k_logp(const double *__restrict__ p, double *__restrict__ out, size_t n, int skip_zero)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= n) return;
+	const double v = p[idx];
+	out[idx] = (skip_zero && v == 0.0) ? 0.0 : log(v);
+}
+
 /* secant: out = x_to - x_from (em_alg.c:1104-1161) */
 __global__ void k_diff(const double *__restrict__ a, const double *__restrict__ b, double *out, size_t n)
 {
@@ -326,7 +337,7 @@ static void free_model(mchip_context *ctx)
 {
 	for (int s = 0; s < 3; s++) { dfree(ctx->d_p[s]); dfree(ctx->d_q[s]); }
 	for (int s = 0; s < MCHIP_MAX_SECANTS; s++) { dfree(ctx->d_up[s]); dfree(ctx->d_vp[s]); dfree(ctx->d_uq[s]); dfree(ctx->d_vq[s]); }
-	dfree(ctx->d_sik); dfree(ctx->d_stage); dfree(ctx->d_Apart); dfree(ctx->d_Spart); dfree(ctx->d_llpart);
+	dfree(ctx->d_sik); dfree(ctx->d_stage); dfree(ctx->d_logp); dfree(ctx->d_Apart); dfree(ctx->d_Spart); dfree(ctx->d_llpart);
 	dfree(ctx->d_redpart); dfree(ctx->d_flags);
 	ctx->K = 0;
 	ctx->kt = nullptr;
@@ -504,7 +515,6 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "set_model before set_genotypes%s", nullptr);
 	if (K < 1) return fail(ctx, MCHIP_ERR_INVALID, "K must be >= 1%s", nullptr);
 	if (K > MCHIP_MAX_K) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "K > MCHIP_MAX_K is not built%s", nullptr);
-	if (!admixture) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "mixture model kernels are not built yet%s", nullptr);
 	if (n_secants < 0 || n_secants > MCHIP_MAX_SECANTS) return fail(ctx, MCHIP_ERR_INVALID, "n_secants out of range%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -531,19 +541,34 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	HIPCHK(hipMalloc((void **)&ctx->d_sik, (size_t)ctx->I * K * sizeof(double)));
 	HIPCHK(hipMemsetAsync(ctx->d_sik, 0, (size_t)ctx->I * K * sizeof(double), ctx->stream));
 	HIPCHK(hipMalloc((void **)&ctx->d_stage, KT * sizeof(double)));
+	if (!admixture) HIPCHK(hipMalloc((void **)&ctx->d_logp, KT * sizeof(double)));
 
-	/* launch geometry: about 8 workgroups per CU for each pass, chunk sizes multiples of 8 */
-	const int target = 8 * ctx->n_cu;
+	/* launch geometry.  Both passes are FP64-issue-bound and every workgroup does the same amount of work, so
+	 * the grid's last partial "round" of workgroups runs at low occupancy: measured at config 3, 8 workgroups
+	 * per CU cost 6.9 ms per EM step, 64 per CU 5.4 ms (profiles/r01_geometry_sweep.txt).  More chunks mean
+	 * more partial-sum slabs (Apart/Spart are written and re-read once per step), so the chunk count is capped
+	 * where the slab bytes reach ~15 % of the genotype bytes the pass streams.  Chunk sizes are multiples of 8. */
+	int per_cu = 64;
+	if (const char *e = getenv("MCHIP_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;	/* tuning knob */
+	const int target = per_cu * ctx->n_cu;
 	const int col_tiles = (ctx->T + MCHIP_BLOCK - 1) / MCHIP_BLOCK;
+	const int iblocks = (ctx->I + 7) / 8, lblocks = (ctx->L + 7) / 8;
+	const double slab_frac = 0.15;
+	/* column pass: slab bytes per chunk 8*K*T, genotype bytes per chunk ichunk*L*ploidy */
+	int min_ichunk = (int)ceil(8.0 * K * ctx->T / (slab_frac * ctx->L * ctx->ploidy));
 	int want = (target + col_tiles - 1) / col_tiles;
-	int iblocks = (ctx->I + 7) / 8;
+	int cap = ctx->I / (min_ichunk > 0 ? min_ichunk : 1);
+	if (want > cap) want = cap;
 	if (want < 1) want = 1;
 	if (want > iblocks) want = iblocks;
 	ctx->ichunk = ((iblocks + want - 1) / want) * 8;
 	ctx->n_ichunks = (ctx->I + ctx->ichunk - 1) / ctx->ichunk;
+	/* individual pass: slab bytes per chunk 8*K*I, genotype bytes per chunk lchunk*I*ploidy */
 	const int ind_tiles = (ctx->I + 127) / 128;
+	int min_lchunk = (int)ceil(8.0 * K / (slab_frac * ctx->ploidy));
 	want = (target + ind_tiles - 1) / ind_tiles;
-	int lblocks = (ctx->L + 7) / 8;
+	cap = ctx->L / (min_lchunk > 0 ? min_lchunk : 1);
+	if (want > cap) want = cap;
 	if (want < 1) want = 1;
 	if (want > lblocks) want = lblocks;
 	ctx->lchunk = ((lblocks + want - 1) / want) * 8;
@@ -657,8 +682,39 @@ static int finalize_shared_eta(mchip_context *ctx, int to)
 	return MCHIP_OK;
 }
 
+/* mixture model: E step (mode 0, optionally followed by the M step) or logL_mixture (mode 1) */
+static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int mode)
+{
+	const size_t KT = (size_t)ctx->K * ctx->T;
+	hipLaunchKernelGGL(k_logp, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[from], ctx->d_logp, KT, mode == 0);
+	mchip_pass_args a = pass_args(ctx, from);
+	a.P = ctx->d_logp;
+	prof_mark(ctx, mode == 0 ? MCHIP_KERN_ACCUM_Q : MCHIP_KERN_LOGLIK, true);
+	ctx->kt->mix_gather(a, ctx->stream);
+	prof_mark(ctx, mode == 0 ? MCHIP_KERN_ACCUM_Q : MCHIP_KERN_LOGLIK, false);
+	const int nb = (ctx->I + MCHIP_BLOCK - 1) / MCHIP_BLOCK;
+	ctx->kt->mix_finalize(ctx->I, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[from], ctx->d_sik, ctx->d_llpart, mode, ctx->stream);
+	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, nb, ctx->d_scalars + (mode ? 1 : 0));
+	if (do_mstep) {
+		int rc = finalize_shared_eta(ctx, to);		/* em_alg.c:916-962 */
+		if (rc) return rc;
+		mchip_pass_args b = pass_args(ctx, from);
+		b.Q = ctx->d_sik;				/* vik rows */
+		prof_mark(ctx, MCHIP_KERN_ACCUM_P, true);
+		ctx->kt->mix_column(b, ctx->stream);
+		prof_mark(ctx, MCHIP_KERN_ACCUM_P, false);
+		hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
+				   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
+				   0, ctx->p_lb, ctx->do_projection, ctx->p_lb, ctx->d_flags);
+	}
+	HIPCHK(hipGetLastError());
+	if (mode == 0) ctx->have_ll = 1;
+	return MCHIP_OK;
+}
+
 static int run_estep(mchip_context *ctx, int from, int to, int do_mstep)
 {
+	if (!ctx->admixture) return run_mixture(ctx, from, to, do_mstep, 0);
 	mchip_pass_args a = pass_args(ctx, from);
 	if (do_mstep || !ctx->sparse) {
 		prof_mark(ctx, MCHIP_KERN_ACCUM_P, true);
@@ -721,6 +777,11 @@ int mchip_loglik(mchip_context *ctx, int slot, double *loglik)
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(ctx->device));
+	if (!ctx->admixture) {
+		if ((rc = run_mixture(ctx, slot, slot, 0, 1))) return rc;
+		if (loglik) return fetch_scalars(ctx, 1, 1, loglik);
+		return MCHIP_OK;
+	}
 	mchip_pass_args a = pass_args(ctx, slot);
 	prof_mark(ctx, MCHIP_KERN_LOGLIK, true);
 	ctx->kt->loglik(a, ctx->stream);
@@ -737,6 +798,7 @@ int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to
 	int rc = check_slot(ctx, to);
 	if (rc) return rc;
 	if (!assign) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
+	if (!ctx->admixture) return fail(ctx, MCHIP_ERR_STATE, "allele partitions initialise the admixture model only%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t raw_bytes = (size_t)ctx->I * ctx->L * ctx->ploidy;
 	if (!ctx->d_asA) HIPCHK(hipMalloc((void **)&ctx->d_asA, ctx->geno_bytes_A));

@@ -59,6 +59,10 @@ struct mchip_ktable {
 	void (*finalize_q)(int I, int K, int n_lchunks, const double *Spart, const double *Qfrom, int qstride_from,
 			   double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, hipStream_t s);
 	void (*project_q)(int nrows, int K, double *Q, double lb, hipStream_t s);
+	/* mixture model */
+	void (*mix_gather)(const mchip_pass_args &a, hipStream_t s);	/* a.P = log P table; Spart = per-chunk sums */
+	void (*mix_finalize)(int I, int n_lchunks, const double *Vpart, const double *eta, double *vik, double *llpart, int mode, hipStream_t s);
+	void (*mix_column)(const mchip_pass_args &a, hipStream_t s);	/* a.Q = vik; Apart = sum_i vik n */
 };
 
 const mchip_ktable *mchip_get_ktable(int K);

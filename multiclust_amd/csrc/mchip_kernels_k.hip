@@ -364,6 +364,162 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_sparse(mchip_pass_args a)
 	if (threadIdx.x == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }
 
+/* ---------------------------------------------------------------- mixture model (em_alg.c:763-1011)
+ * E step: v_ik = log eta_k + sum_{l,m: n>0} n log p_klm.  log P is tabulated once per step ([T][K], k_logp in
+ * mchip.hip); the per-individual sum is a gather-add over the alleles the individual carries (one add per
+ * allele copy; n copies of the same allele add the same value n times), lane = individual, rows staged in LDS
+ * exactly like the sparse admixture pass.  Vpart (= Spart) holds the per-locus-chunk sums. */
+template <int PL, bool STAGED>
+__global__ __launch_bounds__(QBLOCK) void k_mix_gather(mchip_pass_args a)
+{
+	extern __shared__ __attribute__((aligned(16))) double lds[];
+	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
+	const bool active = i_raw < a.I;
+	const int i = active ? i_raw : a.I - 1;
+	const int pl = PL ? PL : a.ploidy;
+	double acc[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) acc[k] = 0.0;
+	const int l0 = blockIdx.y * a.lchunk;
+	const int l1 = min(a.L, l0 + a.lchunk);
+	const int lb0 = l0 >> 3, lb_end = (l1 + 7) >> 3;
+	if (STAGED) {
+		const int c_lo = a.toff[lb0 * 8], c_hi = a.toff[min(lb0 * 8 + 8, a.L)];
+		const int nel = (c_hi - c_lo) * K;
+		for (int x = threadIdx.x; x < nel; x += QBLOCK)
+			lds[(x / K) * KP + (x % K)] = a.P[(size_t)c_lo * K + x];
+		__syncthreads();
+	}
+	for (int lb = lb0; lb < lb_end; lb++) {
+		const int buf = (lb - lb0) & 1;
+		const int c_lo = a.toff[lb * 8];
+		const double *tile = STAGED ? lds + (size_t)buf * a.tile_cols * KP : a.P + (size_t)c_lo * K;
+		if (STAGED && lb + 1 < lb_end) {
+			const int n_lo = a.toff[(lb + 1) * 8], n_hi = a.toff[min((lb + 1) * 8 + 8, a.L)];
+			const int nel = (n_hi - n_lo) * K;
+			double *dst = lds + (size_t)(buf ^ 1) * a.tile_cols * KP;
+			for (int x = threadIdx.x; x < nel; x += QBLOCK)
+				dst[(x / K) * KP + (x % K)] = a.P[(size_t)n_lo * K + x];
+		}
+		geno_group<PL> g;
+		g.load(a.gtS, (size_t)lb * a.I + i, pl);
+		for (int j = 0; j < 8; j++) {
+			const int l = lb * 8 + j;
+			if (l >= l1) break;
+			const int base = a.toff[l] - c_lo;
+			for (int b = 0; b < pl; b++) {
+				const unsigned mraw = g.copy(j, b, pl);
+				if (mraw == MCHIP_MISSING || !active) continue;
+				const double *pr = tile + (size_t)(base + (int)mraw) * (STAGED ? KP : K);
+#pragma unroll
+				for (int k = 0; k < K; k++) acc[k] += pr[k];
+			}
+		}
+		if (STAGED) __syncthreads();
+	}
+	if (active) {
+		double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
+#pragma unroll
+		for (int k = 0; k < K; k++) out[k] = acc[k];
+	}
+}
+
+/* per individual: combine the chunk sums, then
+ *   mode 0 (e_step_mixture, em_alg.c:828-882): v = log eta + sum; max; vik = exp(v - max) / sum; ll_i = log(sum) + max
+ *   mode 1 (logL_mixture, log_likelihood.c:203-228): v = sum + log eta; scale only if exp(max) under/overflows */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_mix_finalize(int I, int n_lchunks, const double *__restrict__ Vpart,
+		const double *__restrict__ eta, double *vik, double *llpart, int mode)
+{
+	__shared__ double red[MCHIP_BLOCK];
+	const int i = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
+	double ll = 0.0;
+	if (i < I) {
+		double v[K];
+		if (mode == 0) {
+#pragma unroll
+			for (int k = 0; k < K; k++) v[k] = log(eta[k]);
+		} else {
+#pragma unroll
+			for (int k = 0; k < K; k++) v[k] = 0.0;
+		}
+		for (int ch = 0; ch < n_lchunks; ch++) {
+			const double *src = Vpart + ((size_t)ch * I + i) * K;
+#pragma unroll
+			for (int k = 0; k < K; k++) v[k] += src[k];
+		}
+		if (mode == 1) {
+#pragma unroll
+			for (int k = 0; k < K; k++) v[k] += log(eta[k]);
+		}
+		double mx = -INFINITY;
+#pragma unroll
+		for (int k = 0; k < K; k++) if (v[k] > mx) mx = v[k];
+		if (mode == 0) {
+			double temp = 0.0;
+#pragma unroll
+			for (int k = 0; k < K; k++) {
+				v[k] = exp(v[k] - mx);
+				temp += v[k];
+			}
+#pragma unroll
+			for (int k = 0; k < K; k++) vik[(size_t)i * K + k] = v[k] / temp;
+			ll = log(temp) + mx;
+		} else {
+			double temp_exp = exp(mx), scale_exp = 0.0;
+			if (temp_exp == 0.0 || temp_exp == HUGE_VAL) {
+				scale_exp = (temp_exp == HUGE_VAL) ? mx : -mx;
+				do {
+					scale_exp *= 0.5;
+					temp_exp = exp(scale_exp);
+				} while (temp_exp == HUGE_VAL);
+				scale_exp = mx - scale_exp;
+#pragma unroll
+				for (int k = 0; k < K; k++) v[k] -= scale_exp;
+			}
+			temp_exp = 0.0;
+#pragma unroll
+			for (int k = 0; k < K; k++) temp_exp = temp_exp + exp(v[k]);
+			ll = log(temp_exp) + scale_exp;
+		}
+	}
+	const double tot = block_sum<MCHIP_BLOCK>(ll, red);
+	if (threadIdx.x == 0) llpart[blockIdx.x] = tot;
+}
+
+/* M step numerators: sum_i vik * n_ic (em_alg.c:972-986), lane = allele column, vik row wave-uniform */
+template <int PL>
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_mix_column(mchip_pass_args a)
+{
+	const int c_raw = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
+	const bool valid = c_raw < a.T;
+	const int c = valid ? c_raw : a.T - 1;
+	const int l = a.col_locus[c];
+	const unsigned m = valid ? (unsigned)a.col_allele[c] : 0xFEu;
+	const int pl = PL ? PL : a.ploidy;
+	double acc[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) acc[k] = 0.0;
+	const int i0 = blockIdx.y * a.ichunk;
+	const int i1 = min(a.I, i0 + a.ichunk);
+	for (int ib = i0 >> 3; ib < ((i1 + 7) >> 3); ib++) {
+		geno_group<PL> g;
+		g.load(a.gtA, (size_t)ib * a.L + l, pl);
+#pragma unroll 4
+		for (int j = 0; j < 8; j++) {
+			const int i = min(ib * 8 + j, a.I - 1);
+			const double *__restrict__ v = a.Q + (size_t)i * K;	/* vik row, wave-uniform */
+			const double n = (double)g.count(j, m, pl);
+#pragma unroll
+			for (int k = 0; k < K; k++) acc[k] = __builtin_fma(v[k], n, acc[k]);
+		}
+	}
+	if (valid) {
+		double *out = a.Apart + ((size_t)blockIdx.y * a.T + c) * K;
+#pragma unroll
+		for (int k = 0; k < K; k++) out[k] = acc[k];
+	}
+}
+
 /* ---------------------------------------------------------------- hard partition (first M step)
  * rnd_init.c:456-482: d[i][k][l][m] = 1 for every copy a of allele m assigned to cluster k. */
 template <int PL>
@@ -545,6 +701,26 @@ void launch_accum_q(const mchip_pass_args &a, hipStream_t s)
 	if (a.ploidy == 2) hipLaunchKernelGGL((k_individual_pass<2>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
 	else hipLaunchKernelGGL((k_individual_pass<0>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
 }
+void launch_mix_gather(const mchip_pass_args &a, hipStream_t s)
+{
+	const size_t lds = 2 * (size_t)a.tile_cols * KP * sizeof(double);
+	if (a.sparse) {
+		if (a.ploidy == 2) hipLaunchKernelGGL((k_mix_gather<2, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
+		else hipLaunchKernelGGL((k_mix_gather<0, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
+	} else {
+		if (a.ploidy == 2) hipLaunchKernelGGL((k_mix_gather<2, false>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
+		else hipLaunchKernelGGL((k_mix_gather<0, false>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
+	}
+}
+void launch_mix_finalize(int I, int n_lchunks, const double *Vpart, const double *eta, double *vik, double *llpart, int mode, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_mix_finalize, dim3((I + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s, I, n_lchunks, Vpart, eta, vik, llpart, mode);
+}
+void launch_mix_column(const mchip_pass_args &a, hipStream_t s)
+{
+	if (a.ploidy == 2) hipLaunchKernelGGL((k_mix_column<2>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+	else hipLaunchKernelGGL((k_mix_column<0>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+}
 void launch_part_p(const mchip_pass_args &a, hipStream_t s)
 {
 	if (a.ploidy == 2) hipLaunchKernelGGL((k_partition_columns<2>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
@@ -575,6 +751,7 @@ const mchip_ktable *MCHIP_CAT(mchip_ktable_get_, MCHIP_K)()
 {
 	static mchip_ktable t = {
 		launch_accum_p, launch_loglik, launch_accum_q, launch_part_p, launch_part_q, launch_finalize_q, launch_project_q,
+		launch_mix_gather, launch_mix_finalize, launch_mix_column,
 	};
 	return &t;
 }

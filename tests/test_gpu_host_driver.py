@@ -19,7 +19,7 @@ def make_fit(g, accel=0, **kw):
 
 
 @pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "tetra_admix_k3", "missing_admix_k3",
-                                  "multi_admix_k1", "multi_admix_c_k3"])
+                                  "multi_admix_k1", "multi_admix_c_k3", "multi_mix_k3", "missing_mix_k2"])
 def test_em_to_convergence(name):
     g = Golden(name)
     fit = make_fit(g)

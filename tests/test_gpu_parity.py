@@ -131,3 +131,49 @@ def test_invalid_inputs_are_rejected(ctx):
         ctx.set_model(17)                   # K > MCHIP_MAX_K
     with pytest.raises(mc.HipError):
         ctx.set_model(0)
+
+
+MIX = ["multi_mix_k3", "missing_mix_k2"]
+
+
+@pytest.mark.parametrize("name", MIX)
+def test_mixture_em_steps_vs_reference_golden(ctx, name):
+    """e_step_mixture / m_step_mixture / logL_mixture (em_alg.c:763-1011, log_likelihood.c:157-232)."""
+    g = Golden(name)
+    setup_case(ctx, g)
+    ll_ref = g.f64("em_ll.f64")
+    snaps = set(g.m["snapshots"])
+    for s in range(1, g.m["n_em_steps"] + 1):
+        ll = ctx.em_step(0, 0)
+        assert abs(ll - ll_ref[s - 1]) <= 1e-8, (s, ll, ll_ref[s - 1])
+        if s in snaps:
+            rtol, atol = (1e-11, 1e-14) if s == 1 else (1e-7, 1e-12)
+            close(ctx.get_q(0), g.q("step%d" % s), rtol, atol)
+            close(ctx.get_p(0), g.p("step%d" % s), rtol, atol)
+            close(ctx.expected_counts(), g.sik("step%d" % s), 1e-7, 1e-12)      # vik
+    assert abs(ctx.loglik(0) - g.m["ll_after_em"]) <= 1e-8
+
+
+def test_mixture_vs_oracle_synthetic(ctx):
+    I, L, K = 300, 700, 6
+    ua, geno = make_dataset(I, L, K, ploidy=2, max_alleles=5, seed=77, missing=0.01)
+    lb = ob.lib.mco_lower_bound(1e-8, I, 2)
+    _, p0 = random_params(I, ua, K, seed=3, lower_bound=lb)
+    eta0 = np.full(K, 1.0 / K)
+    opt = ob.make_options(admixture=0, lower_bound=lb, abs_error=0.0)
+    mod = ob.Model(ob.Data(I, L, 2, ua, geno), opt, K)
+    mod.q(0)[...] = eta0
+    mod.p(0)[...] = p0
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, admixture=0, lower_bound=lb)
+    ctx.set_q(0, eta0)
+    ctx.set_p(0, p0)
+    for s in range(1, 5):
+        mod.em_step()
+        ll = ctx.em_step(0, 0)
+        assert abs(ll - mod.logL) <= 1e-12 * abs(mod.logL) + 1e-8
+        # posteriors close to 0/1 amplify last-bit differences of the log-sums; 10x inside north_star's 1e-6
+        close(ctx.get_q(0), mod.q(0), 1e-7, 1e-13)
+        close(ctx.get_p(0), mod.p(0), 1e-7, 1e-13)
+        close(ctx.expected_counts(), mod.sik(), 1e-7, 1e-12)
+    assert abs(ctx.loglik(0) - mod.loglik(0)) <= 1e-12 * abs(mod.logL) + 1e-8
