@@ -163,15 +163,16 @@ def main():
                    abs_error=1e-300)          # never "converges": exactly K timed steps
     hlib = hip.load()
     ctx = C.c_void_p(fit.mod.dev)
-    # one initialisation per rank: random allele partition (rnd_init.c:456-482) drawn with a per-rank seed,
-    # first M step on the device (the glibc-stream jump-ahead that gives the serial program's draws is a
-    # "next" row)
-    rng = np.random.default_rng(1234567 + rank)
-    assign = rng.integers(0, w["K"], size=geno.shape, dtype=np.uint8)
-    rc = hlib.mchip_mstep_from_partition(ctx, assign.ctypes.data, 0)
+    # one initialisation per rank = unit `rank` of the serial program: random allele partition (rnd_init.c:456-482)
+    # drawn from the glibc-compatible stream jumped ahead to unit * I*L*ploidy draws (mc_rng_jump), first M step on
+    # the device (mchip_mstep_from_partition).  Not timed (the metric is the EM loop).
+    rng = host.McRng()
+    hostlib = host.load()
+    hostlib.mc_srand(C.byref(rng), 1234567)
+    hostlib.mc_rng_jump(C.byref(rng), rank * hostlib.mc_draws_per_init(C.byref(fit.opt), C.byref(fit.dat), w["K"]))
+    rc = hostlib.mc_initialize_model(C.byref(fit.opt), C.byref(fit.dat), fit.mp, C.byref(rng))
     if rc:
-        raise SystemExit("mstep_from_partition failed: %s" % hlib.mchip_last_error(ctx).decode())
-    del assign
+        raise SystemExit("mc_initialize_model failed: %s" % hlib.mchip_last_error(ctx).decode())
 
     iters_per_step = 2 if accel else 1
 

@@ -37,6 +37,18 @@ class McRng(C.Structure):
     _fields_ = [("r", C.c_int32 * 31), ("f", C.c_int), ("b", C.c_int)]
 
 
+class McUnitResult(C.Structure):
+    _fields_ = [("unit", C.c_int), ("logL", C.c_double), ("converged", C.c_int), ("n_iter", C.c_int),
+                ("time_stop", C.c_int), ("iter_stop", C.c_int), ("pindex", C.c_int), ("fatal", C.c_int)]
+
+
+class McSummary(C.Structure):
+    _fields_ = [("n_init", C.c_int), ("n_total_iter", C.c_int), ("n_max_iter", C.c_int),
+                ("n_maxll_times", C.c_int), ("n_maxll_init", C.c_int), ("ever_converged", C.c_int),
+                ("best_unit", C.c_int), ("max_logL", C.c_double), ("first_max_logL", C.c_double),
+                ("aic", C.c_double), ("bic", C.c_double)]
+
+
 _lib = None
 
 
@@ -70,6 +82,12 @@ def load():
     lib.mc_log_likelihood.restype = C.c_double
     lib.mc_srand.argtypes = [C.POINTER(McRng), C.c_uint]
     lib.mc_rand.argtypes = [C.POINTER(McRng)]
+    lib.mc_rng_jump.argtypes = [C.POINTER(McRng), C.c_uint64]
+    lib.mc_summary_reset.argtypes = [C.POINTER(McSummary)]
+    lib.mc_summary_add.argtypes = [OP, C.POINTER(McSummary), C.POINTER(McUnitResult), C.c_int, C.c_int]
+    lib.mc_draws_per_init.argtypes = [OP, DP, C.c_int]
+    lib.mc_draws_per_init.restype = C.c_uint64
+    lib.mc_fit_unit.argtypes = [OP, DP, MP, C.c_uint, C.c_int, C.POINTER(McUnitResult)]
     lib.mc_no_parameters.argtypes = [OP, DP, C.c_int]
     lib.mc_aic.restype = C.c_double
     lib.mc_aic.argtypes = [C.c_double, C.c_int]
@@ -160,6 +178,17 @@ class Fit:
 
     def accelerated_em_step(self):
         return self.lib.mc_accelerated_em_step(*self._a())
+
+    def fit_unit(self, seed, unit):
+        """initialisation `unit` of the run seeded with `seed` (stream jumped to the serial program's offset) + em()"""
+        r = McUnitResult()
+        rc = self.lib.mc_fit_unit(C.byref(self.opt), C.byref(self.dat), self.mp, seed, unit, C.byref(r))
+        if rc:
+            raise hip.HipError("mc_fit_unit failed (%d)" % rc)
+        return r
+
+    def no_parameters(self):
+        return self.lib.mc_no_parameters(C.byref(self.opt), C.byref(self.dat), self.K)
 
     def log_likelihood(self, which):
         return self.lib.mc_log_likelihood(C.byref(self.opt), C.byref(self.dat), self.mp, which)

@@ -75,6 +75,11 @@ typedef struct mc_rng { int32_t r[31]; int f, b; } mc_rng;
 void mc_srand(mc_rng *g, unsigned int seed);
 int mc_rand(mc_rng *g);
 
+/* advance the stream by n draws in O(31^2 log n): the generator is the linear recurrence
+ * x_j = x_{j-31} + x_{j-3} (mod 2^32), so x^n mod (x^31 - x^28 - 1) gives the state n steps ahead.  This is
+ * what lets unit u of a sharded run start exactly where the serial program would. */
+void mc_rng_jump(mc_rng *g, uint64_t n);
+
 void mc_make_options(mc_options *opt);				/* defaults of make_options, multiclust.c:902-978 */
 int mc_synchronize(mc_options *opt, const mc_data *dat);	/* lower bounds + q, multiclust.c:812-820 */
 
@@ -106,6 +111,26 @@ double mc_qn_accelerated_update(const mc_options *opt, const mc_data *dat, mc_mo
 double mc_aic(double max_logL, int no_parameters);			/* log_likelihood.c:70 */
 double mc_bic(double max_logL, int no_parameters, int I);		/* log_likelihood.c:82 */
 int mc_no_parameters(const mc_options *opt, const mc_data *dat, int K);	/* multiclust.c:1267-1276 */
+
+/* ---- several initialisations: maximize_likelihood (multiclust.c:471-656) ---- */
+typedef struct mc_unit_result {	/* what one initialisation + em() leaves behind */
+	int unit;
+	double logL;
+	int converged, n_iter, time_stop, iter_stop, pindex, fatal;
+} mc_unit_result;
+
+typedef struct mc_summary {	/* state maintained across initialisations (multiclust.h:337-353) */
+	int n_init, n_total_iter, n_max_iter, n_maxll_times, n_maxll_init, ever_converged, best_unit;
+	double max_logL, first_max_logL, aic, bic;
+} mc_summary;
+
+void mc_summary_reset(mc_summary *s);						/* multiclust.c:477-486 */
+/* multiclust.c:534-560; results must be fed in unit order to reproduce the serial program */
+void mc_summary_add(const mc_options *opt, mc_summary *s, const mc_unit_result *r, int no_parameters, int I);
+/* rand() draws one admixture initialisation consumes (rnd_init.c:460-467: one per allele copy, missing included) */
+uint64_t mc_draws_per_init(const mc_options *opt, const mc_data *dat, int K);
+/* initialisation `unit` of a run seeded with `seed`: jump the stream to unit * draws_per_init, initialise, em() */
+int mc_fit_unit(const mc_options *opt, const mc_data *dat, mc_model *mod, unsigned int seed, int unit, mc_unit_result *out);
 
 #ifdef __cplusplus
 }

@@ -911,3 +911,69 @@ void mco_em(const mco_data *d, const mco_options *o, mco_model *m)
 			stop = mco_accelerated_em_step(d, o, m, NULL);
 	} while (!stop);
 }
+
+/* ------------------------------------------------------------------ multiclust.c:471-656 */
+
+void mco_summary_reset(mco_summary *s)
+{
+	/* multiclust.c:478-486; max_logL is reset by estimate_model (377) */
+	s->first_max_logL = -INFINITY;
+	s->max_logL = -INFINITY;
+	s->n_init = 0;
+	s->n_total_iter = 0;
+	s->n_maxll_times = 0;
+	s->n_maxll_init = -1;
+	s->n_max_iter = 0;
+	s->ever_converged = 0;
+	s->best_unit = -1;
+}
+
+void mco_summary_add(const mco_options *o, mco_summary *s, int unit, double logL, int conv, int n_iter, int time_stop)
+{
+	/* multiclust.c:534-560 */
+	if (conv) s->ever_converged = 1;
+	if (conv || (!s->n_init && time_stop)) {
+		s->n_total_iter += n_iter;
+		if (s->n_max_iter < n_iter) s->n_max_iter = n_iter;
+		s->n_init++;
+	}
+	/* converged(opt, mod, first_max_logL) with mod->logL = logL (em_alg.c:163-182) */
+	int seen = 1;
+	double abs_diff = 0, rel_diff = 0;
+	if (o->abs_error) abs_diff = fabs(s->first_max_logL - logL);
+	if (o->rel_error) rel_diff = abs_diff / fabs(logL);
+	if (o->abs_error && abs_diff > o->abs_error) seen = 0;
+	if (o->rel_error && rel_diff > o->rel_error) seen = 0;
+	if (conv && seen) {
+		s->n_maxll_times++;
+	} else if (conv && logL > s->first_max_logL) {
+		s->n_maxll_times = 1;
+		s->first_max_logL = logL;
+		s->n_maxll_init = s->n_init;
+	}
+	if (logL > s->max_logL) {
+		s->max_logL = logL;
+		s->best_unit = unit;
+	}
+}
+
+void mco_maximize_likelihood(const mco_data *d, const mco_options *o, mco_model *m, mco_rng *g, int n_units,
+			     double *per_unit, mco_summary *s)
+{
+	mco_summary_reset(s);
+	for (int u = 0; u < n_units; u++) {
+		/* multiclust.c:518-524; note delta_index is NOT reset between initialisations */
+		int delta_keep = m->delta_index;
+		mco_model_reset(m);
+		m->delta_index = delta_keep;
+		m->logL = 0.0;
+		mco_random_initialize_admixture(d, o, m, g);
+		m->logL = -INFINITY;	/* initialize_model, rnd_init.c:59 */
+		mco_em(d, o, m);
+		if (per_unit) {
+			per_unit[4 * u + 0] = m->logL; per_unit[4 * u + 1] = m->converged;
+			per_unit[4 * u + 2] = m->n_iter; per_unit[4 * u + 3] = m->pindex;
+		}
+		mco_summary_add(o, s, u, m->logL, m->converged, m->n_iter, 0);
+	}
+}

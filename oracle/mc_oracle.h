@@ -97,6 +97,18 @@ int mco_accelerated_em_step(const mco_data *d, const mco_options *o, mco_model *
 /* em_alg.c:44-90 */
 void mco_em(const mco_data *d, const mco_options *o, mco_model *m);
 
+/* maximize_likelihood bookkeeping over initialisations (multiclust.c:477-486, 534-560) */
+typedef struct mco_summary {
+	int n_init, n_total_iter, n_max_iter, n_maxll_times, n_maxll_init, ever_converged, best_unit;
+	double max_logL, first_max_logL;
+} mco_summary;
+void mco_summary_reset(mco_summary *s);
+void mco_summary_add(const mco_options *o, mco_summary *s, int unit, double logL, int converged, int n_iter, int time_stop);
+/* n_units initialisations from one continuing rand() stream, each followed by em(); per_unit[u] = {logL, converged,
+ * n_iter, pindex} */
+void mco_maximize_likelihood(const mco_data *d, const mco_options *o, mco_model *m, mco_rng *g, int n_units,
+			     double *per_unit, mco_summary *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ double step_size(options *opt, data *dat, model *mod);
 double accelerated_update(options *opt, data *dat, model *mod, double s);
 double qn_accelerated_update(options *opt, data *dat, model *mod);
 void michelot_project(double *, int, double, double);
+int maximize_likelihood(options *opt, data *dat, model *mod, int bootstrap);
 
 static const char *outdir;
 static FILE *man;
@@ -393,6 +394,45 @@ int main(int argc, const char **argv)
 		}
 		fclose(fi); fclose(fo); fclose(fl);
 		man_int("proj_cases", ncase);
+	}
+
+	/* ---- section 5: several initialisations from ONE continuing rand() stream (maximize_likelihood,
+	 * multiclust.c:471-656): per-initialisation results from our own loop of the same calls, and the
+	 * reference's own bookkeeping summary from maximize_likelihood() itself ---- */
+	if (mod->K > 1 && opt->admixture) {
+		const int n_units = 6;
+		int saved_n_init = opt->n_init;
+		opt->accel_scheme = accel_saved;
+		f = xopen("multi_init.f64");
+		srand(opt->seed);
+		for (int u = 0; u < n_units; u++) {
+			double rec[4];
+			mod->current_i = mod->current_l = mod->current_k = 0;
+			mod->logL = 0.0; mod->converged = 0; mod->stopped = 0; mod->iter_stop = 0;
+			mod->delta_index = 0;
+			initialize_model(opt, dat, mod);
+			em(opt, dat, mod);
+			rec[0] = mod->logL; rec[1] = mod->converged; rec[2] = mod->n_iter; rec[3] = mod->pindex;
+			fwrite(rec, sizeof(double), 4, f);
+		}
+		fclose(f);
+		man_key("rand_after_multi_init"); fprintf(man, "%d", rand());
+		srand(opt->seed);
+		opt->n_init = n_units;
+		mod->max_logL = -INFINITY;
+		mod->delta_index = 0;
+		maximize_likelihood(opt, dat, mod, 0);
+		opt->n_init = saved_n_init;
+		man_int("mi_units", n_units);
+		man_int("mi_n_init", mod->n_init);
+		man_int("mi_n_total_iter", mod->n_total_iter);
+		man_int("mi_n_max_iter", mod->n_max_iter);
+		man_int("mi_n_maxll_times", mod->n_maxll_times);
+		man_int("mi_n_maxll_init", mod->n_maxll_init);
+		man_int("mi_ever_converged", mod->ever_converged);
+		man_dbl("mi_max_logL", mod->max_logL); man_hex("mi_max_logL_hex", mod->max_logL);
+		man_dbl("mi_first_max_logL", mod->first_max_logL);
+		man_dbl("mi_aic", mod->aic); man_dbl("mi_bic", mod->bic);
 	}
 
 	fprintf(man, "\n}\n");

@@ -22,6 +22,12 @@ class Rng(C.Structure):
     _fields_ = [("r", C.c_int32 * 31), ("f", C.c_int), ("b", C.c_int)]
 
 
+class Summary(C.Structure):
+    _fields_ = [("n_init", C.c_int), ("n_total_iter", C.c_int), ("n_max_iter", C.c_int), ("n_maxll_times", C.c_int),
+                ("n_maxll_init", C.c_int), ("ever_converged", C.c_int), ("best_unit", C.c_int),
+                ("max_logL", C.c_double), ("first_max_logL", C.c_double)]
+
+
 def _load():
     if not os.path.exists(_LIB):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "libmc_oracle.so"], check=True)
@@ -70,6 +76,9 @@ def _load():
     lib.mco_accelerated_em_step.argtypes = [vp, C.POINTER(Options), vp, dp]
     lib.mco_accelerated_em_step.restype = i32
     lib.mco_em.argtypes = [vp, C.POINTER(Options), vp]
+    lib.mco_summary_reset.argtypes = [C.POINTER(Summary)]
+    lib.mco_summary_add.argtypes = [C.POINTER(Options), C.POINTER(Summary), i32, C.c_double, i32, i32, i32]
+    lib.mco_maximize_likelihood.argtypes = [vp, C.POINTER(Options), vp, C.POINTER(Rng), i32, dp, C.POINTER(Summary)]
     return lib
 
 
@@ -150,6 +159,21 @@ class Model:
         return stop, list(tr)
 
     def em(self):
+        lib.mco_em(self.data.h, C.byref(self.opt), self.h)
+
+    def maximize_likelihood(self, seed, n_units):
+        rng = Rng()
+        lib.mco_srand(C.byref(rng), seed)
+        per = np.zeros((n_units, 4))
+        s = Summary()
+        lib.mco_maximize_likelihood(self.data.h, C.byref(self.opt), self.h, C.byref(rng), n_units,
+                                    per.ctypes.data_as(C.POINTER(C.c_double)), C.byref(s))
+        return per, s, lib.mco_rand(C.byref(rng))
+
+    def fit_from_rng(self, rng):
+        """one initialisation from a given stream state + em() (what one sharded unit does)"""
+        lib.mco_model_reset(self.h)
+        lib.mco_random_initialize_admixture(self.data.h, C.byref(self.opt), self.h, C.byref(rng))
         lib.mco_em(self.data.h, C.byref(self.opt), self.h)
 
     logL = property(lambda s: lib.mco_model_logL(s.h))

@@ -140,3 +140,26 @@ def test_em_e_step_returns_post_step_loglik():
     assert abs(ll - g.f64("em_ll.f64")[1]) <= 1e-8          # logL entering step 2 = logL after step 1
     np.testing.assert_allclose(fit.expected_counts().sum(), g.I * g.L * g.ploidy, rtol=1e-12)
     fit.close()
+
+
+@pytest.mark.parametrize("name", ["multi_admix_k4", "missing_admix_k3"])
+def test_fit_units_with_jump_ahead_vs_serial_reference(name):
+    """mc_fit_unit: unit u starts from the serial program's stream position (jump-ahead), is initialised and fitted on
+    the GPU; per-unit results and the replayed bookkeeping against the reference's maximize_likelihood()."""
+    from multiclust_amd import shard
+    g = Golden(name)
+    ref = g.f64("multi_init.f64").reshape(-1, 4)
+    fit = host.Fit(g.ua, g.geno, g.K, admixture=1, accel_scheme=g.m["accel_scheme"], verbosity=1)
+    results = []
+    for u in reversed(range(g.m["mi_units"])):          # any order: units are independent
+        r = fit.fit_unit(g.m["seed"], u)
+        assert r.fatal == 0 and r.converged == 1
+        # same starting point as the reference; the SQUAREM path may differ through accept ties (see above)
+        assert abs(r.logL - ref[u, 0]) <= 5e-2, (u, r.logL, ref[u, 0])
+        results.append(r)
+    results.sort(key=lambda r: r.unit)
+    s = shard.replay(results, fit.opt, fit.no_parameters(), g.I)
+    assert s.n_init == g.m["mi_n_init"] and s.ever_converged == 1
+    assert abs(s.max_logL - g.m["mi_max_logL"]) <= 5e-2
+    assert fit.no_parameters() == g.m["no_parameters"]
+    fit.close()

@@ -168,3 +168,18 @@ def test_accelerated_run(name):
     assert np.array_equal(mod.q(mod.pindex), g.q("accelrun"))
     assert np.array_equal(mod.p(mod.pindex), g.p("accelrun"))
     assert np.array_equal(mod.sik(), g.sik("accelrun"))
+
+
+@pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "missing_admix_k3", "tetra_admix_k3", "multi_admix_c_k3"])
+def test_maximize_likelihood_bookkeeping(name):
+    """Six initialisations from one continuing rand() stream, each run through em(), and the reference's own
+    maximize_likelihood() summary (multiclust.c:471-656): per-unit results and bookkeeping, bit for bit."""
+    g = Golden(name)
+    opt, data, mod = make(g, accel_scheme=g.m["accel_scheme"], abs_error=g.m["abs_error"], rel_error=g.m["rel_error"])
+    per, s, next_rand = mod.maximize_likelihood(g.m["seed"], g.m["mi_units"])
+    ref = g.f64("multi_init.f64").reshape(-1, 4)
+    assert np.array_equal(per, ref)
+    assert next_rand == g.m["rand_after_multi_init"]
+    for k in ("n_init", "n_total_iter", "n_max_iter", "n_maxll_times", "n_maxll_init", "ever_converged"):
+        assert getattr(s, k) == g.m["mi_" + k], k
+    assert s.max_logL == g.m["mi_max_logL"] and s.first_max_logL == g.m["mi_first_max_logL"]
