@@ -37,7 +37,8 @@ struct mchip_context {
 	int I, L, ploidy, T, max_M;
 	int32_t *d_ua, *d_toff, *d_col_locus;
 	uint8_t *d_col_allele;
-	uint8_t *d_gtA, *d_gtS;
+	uint8_t *d_gtA, *d_gtS, *d_gtC;
+	int count_bits, has_missing;
 	size_t geno_bytes_A, geno_bytes_S;
 	uint8_t *d_asA, *d_asS;		/* hard-partition scratch, allocated on first use */
 	/* model */
@@ -106,6 +107,7 @@ __global__ void k_relayout(const uint8_t *__restrict__ raw, int I, int L, int pl
 			v = raw[(i * L + l) * pl + a];
 			const int lim = ua ? ua[l] : limit;
 			if (v != 0xFF && (int)v >= lim) atomicOr(bad, 1);
+			if (v == 0xFF) atomicOr(bad, 2);	/* bit 1: the data set has missing copies */
 		}
 		gtA[idx] = v;
 	}
@@ -118,6 +120,31 @@ __global__ void k_relayout(const uint8_t *__restrict__ raw, int I, int L, int pl
 		const size_t l = lb * 8 + j;
 		gtS[idx] = (l < (size_t)L) ? raw[(i * L + l) * pl + a] : (uint8_t)0xFF;
 	}
+}
+
+/* gtA -> packed counts gtC[g][c]: thread = (group g of G individuals, column c) */
+template <int BITS>
+__global__ void k_build_counts(const uint8_t *__restrict__ gtA, int I, int L, int pl, int T,
+			       const int32_t *__restrict__ col_locus, const uint8_t *__restrict__ col_allele, uint4 *gtC)
+{
+	constexpr int PERWORD = 32 / BITS, G = 4 * PERWORD;
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t ngroups = (size_t)(I + G - 1) / G;
+	if (idx >= ngroups * T) return;
+	const int c = (int)(idx % T);
+	const size_t g = idx / T;
+	const int l = col_locus[c];
+	const unsigned m = col_allele[c];
+	unsigned out[4] = {0, 0, 0, 0};
+	for (int x = 0; x < G; x++) {
+		const size_t i = g * G + x;
+		if (i >= (size_t)I) break;
+		const uint8_t *src = gtA + (((i >> 3) * L + l) * 8 + (i & 7)) * (size_t)pl;
+		unsigned n = 0;
+		for (int b = 0; b < pl; b++) n += (src[b] == m);
+		out[x / PERWORD] |= n << (BITS * (x % PERWORD));
+	}
+	gtC[idx] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 /* host order [K][T] <-> device order [T][K] */
@@ -347,7 +374,7 @@ static void free_model(mchip_context *ctx)
 static void free_data(mchip_context *ctx)
 {
 	dfree(ctx->d_ua); dfree(ctx->d_toff); dfree(ctx->d_col_locus); dfree(ctx->d_col_allele);
-	dfree(ctx->d_gtA); dfree(ctx->d_gtS); dfree(ctx->d_asA); dfree(ctx->d_asS);
+	dfree(ctx->d_gtA); dfree(ctx->d_gtS); dfree(ctx->d_gtC); dfree(ctx->d_asA); dfree(ctx->d_asS);
 	ctx->I = ctx->L = ctx->T = 0;
 }
 
@@ -356,7 +383,7 @@ static mchip_pass_args pass_args(mchip_context *ctx, int slot)
 	mchip_pass_args a;
 	memset(&a, 0, sizeof a);
 	a.I = ctx->I; a.L = ctx->L; a.T = ctx->T; a.ploidy = ctx->ploidy; a.K = ctx->K;
-	a.gtA = ctx->d_gtA; a.gtS = ctx->d_gtS;
+	a.gtA = ctx->d_gtA; a.gtS = ctx->d_gtS; a.gtC = ctx->d_gtC; a.count_bits = ctx->count_bits; a.has_missing = ctx->has_missing;
 	a.ua = ctx->d_ua; a.toff = ctx->d_toff; a.col_locus = ctx->d_col_locus; a.col_allele = ctx->d_col_allele;
 	a.P = ctx->d_p[slot]; a.Q = ctx->d_q[slot]; a.qstride = ctx->qstride;
 	a.ichunk = ctx->ichunk; a.n_ichunks = ctx->n_ichunks; a.Apart = ctx->d_Apart; a.llpart = ctx->d_llpart;
@@ -501,9 +528,26 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	(void)hipFree(d_raw);
 	(void)hipFree(d_bad);
-	if (bad) {
+	if (bad & 1) {
 		free_data(ctx);
 		return fail(ctx, MCHIP_ERR_INVALID, "genotype allele index >= uniquealleles[l]%s", nullptr);
+	}
+	ctx->has_missing = (bad & 2) ? 1 : 0;
+	/* packed per-column allele counts for the column pass */
+	ctx->count_bits = ploidy <= 3 ? 2 : (ploidy <= 15 ? 4 : 0);
+	if (getenv("MCHIP_NO_COUNTS")) ctx->count_bits = 0;
+	if (ctx->count_bits) {
+		const int G = 128 / ctx->count_bits;
+		const size_t nwords = (size_t)((I + G - 1) / G) * T;
+		HIPCHK(hipMalloc((void **)&ctx->d_gtC, nwords * 16));
+		if (ctx->count_bits == 2)
+			hipLaunchKernelGGL(k_build_counts<2>, dim3(nblk(nwords)), dim3(256), 0, ctx->stream, ctx->d_gtA, I, L, ploidy, T,
+					   ctx->d_col_locus, ctx->d_col_allele, (uint4 *)ctx->d_gtC);
+		else
+			hipLaunchKernelGGL(k_build_counts<4>, dim3(nblk(nwords)), dim3(256), 0, ctx->stream, ctx->d_gtA, I, L, ploidy, T,
+					   ctx->d_col_locus, ctx->d_col_allele, (uint4 *)ctx->d_gtC);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipStreamSynchronize(ctx->stream));
 	}
 	return MCHIP_OK;
 }
@@ -561,7 +605,11 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	if (want > cap) want = cap;
 	if (want < 1) want = 1;
 	if (want > iblocks) want = iblocks;
-	ctx->ichunk = ((iblocks + want - 1) / want) * 8;
+	{
+		const int gran = ctx->count_bits ? 128 / ctx->count_bits : 8;	/* individuals per packed word */
+		const int per = (ctx->I + want - 1) / want;
+		ctx->ichunk = ((per + gran - 1) / gran) * gran;
+	}
 	ctx->n_ichunks = (ctx->I + ctx->ichunk - 1) / ctx->ichunk;
 	/* individual pass: slab bytes per chunk 8*K*I, genotype bytes per chunk lchunk*I*ploidy */
 	const int ind_tiles = (ctx->I + 127) / 128;
@@ -700,6 +748,7 @@ static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int m
 		if (rc) return rc;
 		mchip_pass_args b = pass_args(ctx, from);
 		b.Q = ctx->d_sik;				/* vik rows */
+		b.qstride = ctx->K;
 		prof_mark(ctx, MCHIP_KERN_ACCUM_P, true);
 		ctx->kt->mix_column(b, ctx->stream);
 		prof_mark(ctx, MCHIP_KERN_ACCUM_P, false);

@@ -5,6 +5,8 @@
  * Device data layout (all sized for one MI355X, 288 GB HBM3E):
  *   gtA  uint8 [ceil(I/8)][L][8][ploidy]   genotype blocked by 8 individuals: one 8*ploidy-byte load per lane
  *                                           (lane = allele column) serves 8 individuals of the column pass
+ *   gtC  uint4 [ceil(I/G)][T]               packed allele counts n_ic (2 or 4 bits each, G = 64 or 32 individuals per
+ *                                           16-byte word): the column pass reads one word per lane per G individuals
  *   gtS  uint8 [ceil(L/8)][I][8][ploidy]   genotype blocked by 8 loci: one load per lane (lane = individual)
  *                                           serves 8 loci of the individual pass
  *   P    double [T][K]  per slot           allele column c = T_off[l]+m, K contiguous doubles per column
@@ -28,6 +30,9 @@ enum { MCHIP_KERN_ACCUM_P = 0, MCHIP_KERN_ACCUM_Q = 1, MCHIP_KERN_LOGLIK = 2, MC
 struct mchip_pass_args {
 	int I, L, T, ploidy, K;
 	const uint8_t *gtA, *gtS;
+	const uint8_t *gtC;	/* packed allele counts [ceil(I/G)][T] x 16 bytes, G = 128/count_bits; NULL if count_bits == 0 */
+	int count_bits;		/* 2 (ploidy <= 3), 4 (ploidy <= 15) or 0 */
+	int has_missing;	/* any 0xFF byte in the genotype matrix */
 	const int32_t *ua, *toff, *col_locus;
 	const uint8_t *col_allele;
 	const double *P;	/* [T][K] slot read by the E step */

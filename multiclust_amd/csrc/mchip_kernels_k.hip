@@ -26,16 +26,16 @@ namespace {
 
 constexpr int K = MCHIP_K;
 
-/* 1/t to full double precision for t in (0, 1]: hardware seed + two Newton steps (the same recipe the
- * compiler uses inside its IEEE divide, without the scaling/fix-up that denormal or huge inputs need). */
+/* 1/t to full double precision for t in (0, 1]: v_rcp_f64 is good to ~2^-25 (measured 2.1e8 ulp,
+ * scripts/micro/fp64_micro.hip); one second-order step r0 (1 + e + e^2), e = 1 - t r0, leaves e^3 ~ 1e-22 plus
+ * rounding (measured <= 1 ulp), for 3 FMAs instead of the 4 of two Newton steps.  No scaling / fix-up: t is a
+ * convex combination of probabilities >= the lower bound, never denormal or huge. */
 __device__ __forceinline__ double rcp_full(double t)
 {
-	double r = __builtin_amdgcn_rcp(t);
-	double e = __builtin_fma(-t, r, 1.0);
-	r = __builtin_fma(r, e, r);
-	e = __builtin_fma(-t, r, 1.0);
-	r = __builtin_fma(r, e, r);
-	return r;
+	const double r = __builtin_amdgcn_rcp(t);
+	const double e = __builtin_fma(-t, r, 1.0);
+	const double p = __builtin_fma(e, e, e);
+	return __builtin_fma(r, p, r);
 }
 
 /* genotype bytes of sub-entry j (0..7) of an 8-entry group; PL = 2 fast path keeps the group in a uint4 */
@@ -64,6 +64,34 @@ template <> struct geno_group<2> {
 		r.g.y = h ? g.w : g.y;
 		r.g.z = 0xFFFFFFFFu;
 		r.g.w = 0xFFFFFFFFu;
+		return r;
+	}
+};
+
+template <> struct geno_group<4> {	/* tetraploid: 8 entries x 4 bytes = two 16-byte loads */
+	uint4 g0, g1;
+	__device__ __forceinline__ void load(const uint8_t *base, size_t group, int)
+	{
+		const uint4 *p = reinterpret_cast<const uint4 *>(base + group * 32);
+		g0 = p[0];
+		g1 = p[1];
+	}
+	__device__ __forceinline__ unsigned field(int j) const
+	{
+		return (j == 0) ? g0.x : (j == 1) ? g0.y : (j == 2) ? g0.z : (j == 3) ? g0.w
+		     : (j == 4) ? g1.x : (j == 5) ? g1.y : (j == 6) ? g1.z : g1.w;
+	}
+	__device__ __forceinline__ int count(int j, unsigned m, int) const
+	{
+		const unsigned w = field(j);
+		return (int)((w & 0xFFu) == m) + (int)(((w >> 8) & 0xFFu) == m) + (int)(((w >> 16) & 0xFFu) == m) + (int)((w >> 24) == m);
+	}
+	__device__ __forceinline__ unsigned copy(int j, int a, int) const { return (field(j) >> (8 * a)) & 0xFFu; }
+	__device__ __forceinline__ geno_group<4> half(int h) const
+	{
+		geno_group<4> r;
+		r.g0 = h ? g1 : g0;
+		r.g1 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
 		return r;
 	}
 };
@@ -190,6 +218,69 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_pass(mchip_pass_args a)
 	}
 }
 
+/* ---------------------------------------------------------------- column pass on packed allele counts
+ * gtC[g][c] is one 16-byte word per (group of G = 128/BITS individuals, allele column): BITS-bit counts
+ * n_ic = ILM[i][l][m] (BITS = 2 for ploidy <= 3, 4 for ploidy <= 15).  One coalesced 16-byte load per lane serves G
+ * individuals and the count is a single v_bfe_u32, instead of two byte compares, a select and an add per cell.
+ * MIX = false: admixture N-side sums  acc_k += q_ik * n / t;   MIX = true: mixture M step  acc_k += vik * n. */
+template <int BITS, bool MIX>
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a)
+{
+	constexpr int PERWORD = 32 / BITS;		/* individuals per dword */
+	constexpr int G = 4 * PERWORD;			/* individuals per 16-byte word */
+	constexpr unsigned MASK = (1u << BITS) - 1u;
+	const int c_raw = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
+	const bool valid = c_raw < a.T;
+	const int c = valid ? c_raw : a.T - 1;
+	double p[K], acc[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+		p[k] = MIX ? 0.0 : a.P[(size_t)c * K + k];
+		acc[k] = 0.0;
+	}
+	const int i0 = blockIdx.y * a.ichunk;		/* multiple of G */
+	const int i1 = min(a.I, i0 + a.ichunk);
+	const int g_end = (i1 + G - 1) / G;
+	const uint4 *gt = reinterpret_cast<const uint4 *>(a.gtC);
+	uint4 w = gt[(size_t)(i0 / G) * a.T + c];
+	for (int g = i0 / G; g < g_end; g++) {
+		const uint4 wn = gt[(size_t)min(g + 1, g_end - 1) * a.T + c];	/* prefetch (clamped) */
+#pragma unroll 1
+		for (int wi = 0; wi < 4; wi++) {
+			unsigned word = (wi == 0) ? w.x : (wi == 1) ? w.y : (wi == 2) ? w.z : w.w;
+#pragma unroll 1
+			for (int h = 0; h < PERWORD / 4; h++) {
+				const int ibase = g * G + wi * PERWORD + h * 4;
+				if (ibase >= i1) break;		/* wave-uniform; padded individuals have zero counts anyway */
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					const int i = min(ibase + j, a.I - 1);
+					const double *__restrict__ q = a.Q + (size_t)i * a.qstride;	/* wave-uniform: s_load */
+					const double n = (double)((word >> (BITS * j)) & MASK);
+					double r;
+					if (MIX) {
+						r = n;
+					} else {
+						double t = q[0] * p[0];
+#pragma unroll
+						for (int k = 1; k < K; k++) t = __builtin_fma(q[k], p[k], t);
+						r = n * rcp_full(t);
+					}
+#pragma unroll
+					for (int k = 0; k < K; k++) acc[k] = __builtin_fma(q[k], r, acc[k]);
+				}
+				word >>= 4 * BITS;
+			}
+		}
+		w = wn;
+	}
+	if (valid) {
+		double *out = a.Apart + ((size_t)blockIdx.y * a.T + c) * K;
+#pragma unroll
+		for (int k = 0; k < K; k++) out[k] = acc[k];
+	}
+}
+
 /* ---------------------------------------------------------------- individual pass */
 constexpr int QBLOCK = 128;
 
@@ -259,7 +350,7 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
  * stand-alone log-likelihood pass (logL_admixture, log_likelihood.c:96-147). */
 constexpr int KP = (K + 1) & ~1;	/* LDS row stride in doubles: rows stay 16-byte aligned */
 
-template <int PL, bool ACCUM, bool SAFE>
+template <int PL, bool ACCUM, bool SAFE, bool NOMISS>
 __global__ __launch_bounds__(QBLOCK) void k_individual_sparse(mchip_pass_args a)
 {
 	extern __shared__ __attribute__((aligned(16))) double lds[];	/* [2][tile_cols][KP] then [QBLOCK] reduction scratch */
@@ -312,7 +403,8 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_sparse(mchip_pass_args a)
 			for (int b = 0; b < (PL ? PL : 1); b++) {
 				for (int bb = 0; bb < (PL ? 1 : pl); bb++) {	/* generic ploidy: runtime loop over copies */
 					const unsigned mraw = g.copy(j, PL ? b : bb, pl);
-					const bool miss = (mraw == MCHIP_MISSING) || !active;
+					/* NOMISS: the data set has no missing copy: no selects (idle lanes duplicate individual I-1) */
+					const bool miss = NOMISS ? false : ((mraw == MCHIP_MISSING) || !active);
 					const unsigned mm = miss ? 0u : mraw;
 					/* 16-byte LDS reads (ds_read_b128): twice the bytes per LDS cycle of ds_read2_b64 */
 					const double2 *pr = reinterpret_cast<const double2 *>(tile + (size_t)(base + (int)mm) * KP);
@@ -671,6 +763,8 @@ inline dim3 indiv_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK - 1
  * the column pass also produces logL and the individual pass loops over every allele of every locus. */
 void launch_accum_p(const mchip_pass_args &a, hipStream_t s)
 {
+	if (a.sparse && a.count_bits == 2) { hipLaunchKernelGGL((k_column_counts<2, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
+	if (a.sparse && a.count_bits == 4) { hipLaunchKernelGGL((k_column_counts<4, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
 	if (a.sparse) {
 		if (a.ploidy == 2) hipLaunchKernelGGL((k_column_pass<2, true, false, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
 		else hipLaunchKernelGGL((k_column_pass<0, true, false, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
@@ -684,9 +778,18 @@ inline size_t sparse_lds_bytes(const mchip_pass_args &a) { return (2 * (size_t)a
 template <bool ACCUM> void launch_sparse(const mchip_pass_args &a, hipStream_t s)
 {
 	const size_t lds = sparse_lds_bytes(a);
-	if (a.ploidy == 2 && a.flush_blocks >= 1) hipLaunchKernelGGL((k_individual_sparse<2, ACCUM, false>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
-	else if (a.ploidy == 2) hipLaunchKernelGGL((k_individual_sparse<2, ACCUM, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
-	else hipLaunchKernelGGL((k_individual_sparse<0, ACCUM, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
+	const bool nomiss = !a.has_missing;	/* idle lanes of the last block recompute individual I-1 and are dropped at the end */
+	const bool safe = a.flush_blocks < 1;
+#define MCHIP_SPARSE(PLV) \
+	do { \
+		if (nomiss && !safe) hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, false, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a); \
+		else if (!safe) hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, false, false>), indiv_grid(a), dim3(QBLOCK), lds, s, a); \
+		else hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, true, false>), indiv_grid(a), dim3(QBLOCK), lds, s, a); \
+	} while (0)
+	if (a.ploidy == 2) MCHIP_SPARSE(2);
+	else if (a.ploidy == 4) MCHIP_SPARSE(4);
+	else hipLaunchKernelGGL((k_individual_sparse<0, ACCUM, true, false>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
+#undef MCHIP_SPARSE
 }
 void launch_loglik(const mchip_pass_args &a, hipStream_t s)
 {
@@ -718,6 +821,8 @@ void launch_mix_finalize(int I, int n_lchunks, const double *Vpart, const double
 }
 void launch_mix_column(const mchip_pass_args &a, hipStream_t s)
 {
+	if (a.count_bits == 2) { hipLaunchKernelGGL((k_column_counts<2, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
+	if (a.count_bits == 4) { hipLaunchKernelGGL((k_column_counts<4, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
 	if (a.ploidy == 2) hipLaunchKernelGGL((k_mix_column<2>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
 	else hipLaunchKernelGGL((k_mix_column<0>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
 }
