@@ -10,7 +10,9 @@ LIB  = multiclust_amd/lib
 KS   = 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16
 KOBJ = $(foreach k,$(KS),$(OBJ)/mchip_k$(k).o)
 
-all: $(LIB)/libmulticlust_hip.so $(LIB)/libmulticlust_host.so oracle
+BIN  = multiclust_amd/bin
+
+all: $(LIB)/libmulticlust_hip.so $(LIB)/libmulticlust_host.so $(BIN)/multiclust oracle
 
 $(OBJ)/mchip_k%.o: multiclust_amd/csrc/mchip_kernels_k.hip multiclust_amd/csrc/mchip_internal.h include/multiclust_hip.h
 	@mkdir -p $(OBJ)
@@ -24,16 +26,21 @@ $(LIB)/libmulticlust_hip.so: $(OBJ)/mchip.o $(KOBJ)
 	@mkdir -p $(LIB)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
-HOST_SRC = $(wildcard multiclust_amd/host/*.c)
+HOST_SRC = $(filter-out multiclust_amd/host/mc_main.c,$(wildcard multiclust_amd/host/*.c))
 $(LIB)/libmulticlust_host.so: $(HOST_SRC) $(wildcard multiclust_amd/host/*.h) include/multiclust_hip.h $(LIB)/libmulticlust_hip.so
 	@mkdir -p $(LIB)
 	$(CC) $(CFLAGS) -Imulticlust_amd/host -shared -o $@ $(HOST_SRC) -L$(LIB) -lmulticlust_hip -Wl,-rpath,'$$ORIGIN' -lm
+
+# the drop-in command line (same flags, reader and output files as the reference's `multiclust`)
+$(BIN)/multiclust: multiclust_amd/host/mc_main.c $(LIB)/libmulticlust_host.so
+	@mkdir -p $(BIN)
+	$(CC) $(CFLAGS) -Imulticlust_amd/host -o $@ $< -L$(LIB) -lmulticlust_host -lmulticlust_hip -Wl,-rpath,'$$ORIGIN/../lib' -lm
 
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -rf build $(LIB)/*.so
+	rm -rf build $(LIB)/*.so $(BIN)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

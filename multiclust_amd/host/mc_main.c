@@ -1,0 +1,432 @@
+/*
+ * mc_main.c -- the `multiclust` command line on top of the MI355X EM hot path.
+ *
+ * Keeps the reference's observable surface: argv flags as parse_options() reads them (reference
+ * multiclust.c:1396-1735; 2-3 letter disambiguation of --bound/--format/--impute/--missing/--projection/
+ * --plus/--simulate, -I1), defaults of make_options (902-978), the K loop of estimate_model (365-452), the
+ * initialisation loop and bookkeeping of maximize_likelihood (471-656), the per-initialisation stdout line
+ * (618-627), print_model_state (718-793), run_bootstrap (675-708) and the -w repetition summary (201-347).
+ * Deliberately absent (documented in DESIGN.md): -I/-I1 (allele-index mode gives different numbers from default
+ * mode in the reference itself), --impute, --simulate, -x (not implemented in the reference either), -A, -P/-Q.
+ * Extension: --device <n> selects the HIP device.
+ */
+#include "mc_cli.h"
+
+#include <errno.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static const char *accel_abbrev(const mc_cli_options *o, char *buf)
+{
+	static const char *ab[] = { "EM", "S1", "S2", "S3", "QN" };
+	if (o->em.accel_scheme >= MC_QN) { sprintf(buf, "Q%d", o->em.q); return buf; }	/* multiclust.c:828 */
+	return ab[o->em.accel_scheme];
+}
+
+static void usage(FILE *fp, const char *prog)
+{
+	fprintf(fp,
+		"Usage: %s -f <file> [-a] [-k <K> | -1 <minK> -2 <maxK>] [options]\n"
+		"  -a            admixture model (default: mixture)      -c  shared mixing proportions (with -a)\n"
+		"  -k <n>        number of clusters K (default 6)        -1 <n>, -2 <n>  minimum / maximum K\n"
+		"  -n <n>        random initialisations (default 50)     -r <seed>  random seed\n"
+		"  -s <0..6>     acceleration: 0 EM, 1-3 SQUAREM, 4-6 quasi-Newton q=1..3\n"
+		"  -E <d> -e <d> absolute (1e-4) / relative (0) log-likelihood convergence tolerance\n"
+		"  -T <n> -t <m> iteration / time (minutes) limits        -i <n>  initial plain EM iterations\n"
+		"  -g <n>        step-size back-tracking attempts         --bound <d>  parameter lower bound (1e-8)\n"
+		"  --projection  disable the simplex projection           -p <n>  ploidy (default 2)\n"
+		"  -b <n>        parametric bootstrap of H0: K-1 vs HA: K -u l <ll> | n <times>  target log likelihood / revisits\n"
+		"  -w n <n> | t <min> | m <min>   repeat the fit for timing (no files written)\n"
+		"  -d <dir> -o <stem>  output directory / file stem      -R  R-formatted STRUCTURE file\n"
+		"  --missing <n> missing-data code (default -9)           -M  print only the maximum log likelihood\n"
+		"  -v [level]    verbosity                                --device <n>  HIP device index\n", prog);
+}
+
+static int arg_int(int argc, const char **argv, int i, long *out)
+{
+	char *end;
+	if (i >= argc) return 1;
+	errno = 0;
+	*out = strtol(argv[i], &end, 10);
+	return errno || end == argv[i];
+}
+static int arg_dbl(int argc, const char **argv, int i, double *out)
+{
+	char *end;
+	if (i >= argc) return 1;
+	errno = 0;
+	*out = strtod(argv[i], &end);
+	return errno || end == argv[i];
+}
+
+static void defaults(mc_cli_options *o)
+{
+	memset(o, 0, sizeof *o);
+	mc_make_options(&o->em);
+	o->path = "./";
+	o->min_K = o->max_K = 6;
+	o->n_init = 50;
+	o->n_rand_em_init = 50;
+	o->missing_value = MC_MISSING;
+	o->ploidy = 2;
+	o->n_repeat = 1;
+	o->write_files = 1;
+	o->compact = 1;
+}
+
+#define BAD(msg) do { fprintf(stderr, "ERROR [mc_main.c::parse_options]: %s (argument '%s'); try -h\n", msg, i < argc ? argv[i] : ""); return 2; } while (0)
+
+static int parse_options(mc_cli_options *o, int argc, const char **argv)
+{
+	long v;
+	double d;
+	for (int i = 1; i < argc; i++) {
+		if (strlen(argv[i]) < 2) BAD("malformed option");
+		size_t j = 1;
+		char a = argv[i][j];
+		while (a == '-' && ++j < strlen(argv[i])) a = argv[i][j];
+		const char *w = &argv[i][j];
+		switch (a) {
+		case 'a': o->em.admixture = 1; break;
+		case 'b':
+			if (!strncmp(w, "bou", 3)) { if (arg_dbl(argc, argv, ++i, &d) || d < 0) BAD("--bound"); o->em.lower_bound = d; }
+			else { if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-b"); o->n_bootstrap = (int)v; }
+			break;
+		case 'c': o->em.eta_constrained = 1; break;
+		case 'd':
+			if (!strncmp(w, "dev", 3)) { if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("--device"); o->device = (int)v; }
+			else { if (++i >= argc) BAD("-d"); o->path = argv[i]; }
+			break;
+		case 'e': if (arg_dbl(argc, argv, ++i, &d) || d < 0) BAD("-e"); o->em.rel_error = d; break;
+		case 'E': if (arg_dbl(argc, argv, ++i, &d) || d < 0) BAD("-E"); o->em.abs_error = d; break;
+		case 'f':
+			if (!strncmp(w, "fo", 2)) { ++i; break; }	/* --format only matters to the data writer */
+			if (++i >= argc) BAD("-f");
+			o->filename = o->filename_file = argv[i];
+			for (size_t x = strlen(o->filename); x-- > 1;)
+				if (o->filename[x] == '/') { o->filename_file = &o->filename[x + 1]; break; }
+			break;
+		case 'g': if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-g"); o->em.adjust_step = (int)v; break;
+		case 'h': usage(stdout, argv[0]); return 1;
+		case 'i':
+			if (!strncmp(w, "im", 2)) BAD("--impute is not supported by this build");
+			if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-i");
+			o->em.n_init_iter = (int)v;
+			break;
+		case 'I': BAD("-I / -I1 (alleles as indices) is not supported: the reference's own results differ in that mode");
+		case '1': if (arg_int(argc, argv, ++i, &v) || v < 1) BAD("-1"); o->min_K = (int)v; break;
+		case '2': if (arg_int(argc, argv, ++i, &v) || v < 1) BAD("-2"); o->max_K = (int)v; break;
+		case 'k': if (arg_int(argc, argv, ++i, &v) || v < 1) BAD("-k"); o->min_K = o->max_K = (int)v; break;
+		case 'm':
+			if (!strncmp(w, "mi", 2)) { if (arg_int(argc, argv, ++i, &v)) BAD("--missing"); o->missing_value = (int)v; }
+			else { if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-m"); o->n_rand_em_init = (int)v; }	/* stored only */
+			break;
+		case 'M': o->parallel = 1; o->n_repeat = 1; o->em.verbosity = MC_SILENT; break;
+		case 'n': if (arg_int(argc, argv, ++i, &v)) BAD("-n"); o->n_init = (int)v; if (!v) o->n_repeat = 0; break;
+		case 'o': if (++i >= argc) BAD("-o"); o->outfile_name = argv[i]; break;
+		case 'p':
+			if (!strncmp(w, "pr", 2)) o->em.do_projection = 0;
+			else if (!strncmp(w, "pl", 2)) ;	/* --plus: data-writer option */
+			else { if (arg_int(argc, argv, ++i, &v) || v < 1) BAD("-p"); o->ploidy = (int)v; }
+			break;
+		case 'P': case 'Q': case 'A': BAD("-P/-Q/-A side files are not supported by this build");
+		case 'R': o->R_format = 1; break;
+		case 'r': if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-r"); o->em.seed = (unsigned)v; o->seed_given = 1; break;
+		case 'x': BAD("-x (block relaxation) is not implemented, as in the reference");
+		case 's':
+			if (!strncmp(w, "si", 2)) BAD("--simulate is not supported by this build");
+			if (arg_int(argc, argv, ++i, &v) || v < 0 || v > 6) BAD("-s");
+			o->em.accel_scheme = (int)v;
+			break;
+		case 't': if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-t"); o->em.n_seconds = 60u * (unsigned)v; break;
+		case 'T': if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-T"); o->em.max_iter = (int)v; break;
+		case 'u':
+			while (++i < argc && argv[i][0] != '-') {
+				if (argv[i][0] == 'l') { if (arg_dbl(argc, argv, ++i, &d)) BAD("-u l"); o->target_ll = 1; o->desired_ll = d; }
+				else if (argv[i][0] == 'n') { if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-u n"); o->target_revisit = (int)v; }
+				else BAD("-u");
+			}
+			i--;
+			break;
+		case 'v':
+			if (i + 1 == argc) o->em.verbosity = MC_VERBOSE;
+			else if (arg_int(argc, argv, i + 1, &v)) o->em.verbosity = MC_VERBOSE;
+			else { o->em.verbosity = (int)v; i++; }
+			break;
+		case 'w':
+			while (++i < argc && argv[i][0] != '-') {
+				if (arg_int(argc, argv, i + 1, &v)) BAD("-w");
+				if (argv[i][0] == 't') o->repeat_seconds = 60u * (unsigned)v;
+				else if (argv[i][0] == 'm') o->max_repeat_seconds = 60u * (unsigned)v;
+				else if (argv[i][0] == 'n') { if (v <= 0) BAD("-w n"); o->n_repeat = (int)v; }
+				else BAD("-w");
+				i++;
+			}
+			i--;
+			o->write_files = 0;
+			break;
+		default: BAD("unknown option");
+		}
+	}
+	if (!o->filename) {
+		fprintf(stderr, "ERROR [mc_main.c::parse_options]: You must specify the data file with command line option '-f'.  Try '-h' for help.\n");
+		return 2;
+	}
+	return 0;
+}
+
+/* ---- state across initialisations / models (reference struct _model, multiclust.h:337-360) ---- */
+typedef struct run_state {
+	mc_summary sum;
+	double max_logL_H0, ts_obs, ts_bs;
+	int n_targetll_times, n_targetll_init, time_stop;
+	int aic_K, bic_K, null_K, alt_K;
+	double *mle_q, *mle_p;		/* H0 MLEs for the bootstrap (multiclust.c:562-581) */
+	int mle_K;
+	mc_rng rng;
+} run_state;
+
+static void print_model_state(const mc_cli_options *o, const mc_cli_data *d, const run_state *st, int K, int diff, int newline)
+{
+	char ab[16];
+	(void)d;
+	if (o->compact) {	/* multiclust.c:720-746 */
+		printf("%s %s %s %d %u %e %e %e %e %f %f %f ", o->filename, accel_abbrev(o, ab), o->em.admixture ? "admix" : "mix", K,
+		       o->em.seed, o->em.eta_lower_bound, o->em.p_lower_bound, o->em.abs_error, o->em.rel_error,
+		       st->sum.max_logL, st->sum.aic, st->sum.bic);
+		printf("ND ");
+		printf("%s %02d:%02d:%02d %d %d %d %d", st->sum.ever_converged ? "converged" : "not", diff / 3600, (diff % 3600) / 60,
+		       diff % 60, st->sum.n_total_iter, st->sum.n_init, st->sum.n_maxll_init, st->sum.n_maxll_times);
+		if (o->target_ll) printf(" %f %d %d", o->desired_ll, st->n_targetll_init, st->n_targetll_times);
+		if (st->time_stop) printf(" time");
+		if (newline) printf("\n");
+	} else {		/* multiclust.c:748-792 */
+		printf("Dataset: %s\nMethod/Model: %s, %s, K=%d\n", o->filename, accel_abbrev(o, ab), o->em.admixture ? "admix" : "mix", K);
+		printf("Convergence: ae=%e, re=%e\nBounds: e=%e, p=%e\n", o->em.abs_error, o->em.rel_error, o->em.eta_lower_bound, o->em.p_lower_bound);
+		printf("Total number of iterations: %d\nTotal time: %02d:%02d:%02d\n", st->sum.n_total_iter, diff / 3600, (diff % 3600) / 60, diff % 60);
+		printf("Iteration of max log likelihood: %d of %d\nNumber of times reach max log likelihood: %d\n", st->sum.n_maxll_init, st->sum.n_init, st->sum.n_maxll_times);
+		printf("Maximum log likelihood: %f\nAIC: %f\nBIC: %f\nConverged: %s\n", st->sum.max_logL, st->sum.aic, st->sum.bic, st->sum.ever_converged ? "yes" : "no");
+		if (st->time_stop) printf("WARNING: Fitting stopped because ran out of time\n");
+	}
+}
+
+/* maximize_likelihood (multiclust.c:471-656) for one K */
+static int maximize_likelihood(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, mc_model *mod, run_state *st, int bootstrap)
+{
+	const int K = mod->K, nq = (o->em.admixture && !o->em.eta_constrained) ? d->I * K : K;
+	const int npar = mc_no_parameters(&o->em, md, K);
+	double max_logL_keep = st->sum.max_logL;	/* estimate_model resets it per call, not per K (multiclust.c:377) */
+	double *q = NULL, *p = NULL, *sik = NULL;
+	int *count_K = NULL, rc = 0;
+	mc_summary_reset(&st->sum);
+	st->sum.max_logL = max_logL_keep;
+	st->n_targetll_times = 0;
+	st->time_stop = 0;
+	mod->start = clock();
+	const clock_t start = mod->start;
+	for (int i = 0; o->target_revisit || o->target_ll || o->em.n_seconds || i < o->n_init; i++) {
+		const int delta_keep = mod->delta_index;
+		mc_reset_model_state(mod);
+		mod->delta_index = delta_keep;
+		mod->start = start;			/* the time limit spans all initialisations (multiclust.c:488) */
+		if ((rc = mc_initialize_model(&o->em, md, mod, &st->rng))) goto DONE;
+		mc_em(&o->em, md, mod);
+		if (mod->fatal == MC_FATAL_DEVICE) { rc = MCHIP_ERR_HIP; goto DONE; }
+		if (mod->fatal) exit(0);		/* the reference's reaction to NaN / decreasing logL (em_alg.c:106-120) */
+		mc_unit_result r = { i, mod->logL, mod->converged, mod->n_iter, mod->time_stop, mod->iter_stop, mod->pindex, 0 };
+		const double prev_max = st->sum.max_logL;
+		mc_summary_add(&o->em, &st->sum, &r, npar, d->I);
+		if (mod->logL > prev_max) {
+			const int keep_mle = !bootstrap && o->n_bootstrap && K == st->null_K;
+			if (keep_mle || (!bootstrap && o->write_files)) {
+				if (!q) { q = malloc(sizeof(double) * (size_t)nq); p = malloc(sizeof(double) * (size_t)K * d->T);
+					  sik = malloc(sizeof(double) * (size_t)d->I * K); count_K = malloc(sizeof(int) * (size_t)K); }
+				if (!q || !p || !sik || !count_K) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+				if ((rc = mc_model_get_q(mod, mod->pindex, q)) || (rc = mc_model_get_p(mod, mod->pindex, p)) ||
+				    (rc = mc_model_get_expected_counts(mod, sik))) goto DONE;
+			}
+			if (keep_mle) {		/* multiclust.c:562-581 */
+				free(st->mle_q); free(st->mle_p);
+				st->mle_q = malloc(sizeof(double) * (size_t)nq); st->mle_p = malloc(sizeof(double) * (size_t)K * d->T);
+				memcpy(st->mle_q, q, sizeof(double) * (size_t)nq);
+				memcpy(st->mle_p, p, sizeof(double) * (size_t)K * d->T);
+				st->mle_K = K;
+			}
+			if (!bootstrap && o->write_files) {	/* multiclust.c:584-600 */
+				mc_fit_view fv = { K, mod->converged, mod->logL, st->sum.aic, st->sum.bic, q, p, sik };
+				mc_partition(d, &fv, NULL, count_K);
+				if ((rc = mc_write_results(o, d, &fv, count_K))) goto DONE;
+			}
+		}
+		if (!bootstrap && o->em.verbosity > MC_QUIET && o->write_files)	/* multiclust.c:618-627 */
+			printf("K = %d, initialization = %d: %f (%s) in %3d iterations, %02d:%02d:%02d (%f; %d), seed: %u\n", K, i, mod->logL,
+			       mod->converged ? "converged" : "not converged", mod->n_iter, (int)(mod->seconds_run / 3600),
+			       (int)((((int)mod->seconds_run) % 3600) / 60), ((int)mod->seconds_run) % 60, st->sum.max_logL,
+			       st->sum.n_maxll_times, o->em.seed);
+		if (K == 1) break;
+		if (mod->time_stop) { st->time_stop = 1; break; }
+		if (o->target_revisit && st->sum.n_maxll_times >= o->target_revisit) break;
+		if (o->target_ll) {		/* multiclust.c:643-652 */
+			const int hit = mod->logL > o->desired_ll || (o->em.abs_error && fabs(o->desired_ll - mod->logL) <= o->em.abs_error);
+			if (hit) {
+				if (!st->n_targetll_times) st->n_targetll_init = st->sum.n_init;
+				st->n_targetll_times++;
+				if (!o->target_revisit || o->target_revisit <= st->n_targetll_times) break;
+			}
+		}
+	}
+DONE:
+	free(q); free(p); free(sik); free(count_K);
+	return rc;
+}
+
+/* estimate_model (multiclust.c:365-452): K = min_K..max_K, or H0 / HA when bootstrapping */
+static int estimate_model(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, run_state *st, int bootstrap, int *total_iter)
+{
+	int K = o->n_bootstrap ? st->null_K : o->min_K, rc = 0;
+	double min_aic = INFINITY, min_bic = INFINITY;
+	const clock_t start = clock();
+	st->sum.max_logL = -INFINITY;
+	st->max_logL_H0 = -INFINITY;
+	if (total_iter) *total_iter = 0;
+	for (;;) {
+		mc_model *mod = NULL;
+		if ((rc = mc_model_create(&mod, &o->em, md, K, o->device))) return rc;
+		rc = maximize_likelihood(o, d, md, mod, st, bootstrap);
+		mc_model_free(mod);
+		if (rc) return rc;
+		if (o->n_repeat == 1 && o->em.verbosity)
+			print_model_state(o, d, st, K, (int)(((double)clock() - start) / CLOCKS_PER_SEC), 1);
+		if (total_iter) *total_iter += st->sum.n_total_iter;
+		if (o->n_bootstrap && K == st->null_K) st->max_logL_H0 = st->sum.max_logL;
+		if (min_aic > st->sum.aic) { min_aic = st->sum.aic; st->aic_K = K; }
+		if (min_bic > st->sum.bic) { min_bic = st->sum.bic; st->bic_K = K; }
+		if (o->n_bootstrap && K == st->null_K) K = st->alt_K;
+		else if (!o->n_bootstrap && K < o->max_K) K++;
+		else break;
+	}
+	if (o->n_bootstrap) {
+		const double diff = st->sum.max_logL - st->max_logL_H0;
+		if (diff <= 0) {
+			fprintf(stderr, "ERROR [mc_main.c::estimate_model]: Null hypothesis likelihood exceeds alternative hypothesis likelihood.  "
+				"Try increasing number of initializations (command-line option -n)\n");
+			return 3;
+		}
+		if (!bootstrap) st->ts_obs = diff; else st->ts_bs = diff;
+	}
+	return 0;
+}
+
+/* parametric_bootstrap_{admixture,mixture} (bootstrap.c:76-175) in default mode: every (i,l) receives `ploidy`
+ * simulated copies (two rand() per copy for admixture: source cluster, then allele); written as genotype bytes */
+static void bootstrap_genotypes(const mc_cli_options *o, const mc_cli_data *d, run_state *st, uint8_t *geno)
+{
+	const int K = st->mle_K, T = d->T;
+	const int indiv = o->em.admixture && !o->em.eta_constrained;
+	for (int i = 0; i < d->I; i++) {
+		int kmix = 0;
+		if (!o->em.admixture) {
+			double r = (double)mc_rand(&st->rng) / 2147483647.0, sum = 0;
+			while (kmix < K && r > sum) sum += st->mle_q[kmix++];
+			if (kmix) kmix--;
+		}
+		for (int l = 0; l < d->L; l++)
+			for (int n = 0; n < d->ploidy; n++) {
+				int j = kmix;
+				double r, sum;
+				if (o->em.admixture) {
+					r = (double)mc_rand(&st->rng) / 2147483647.0;
+					j = 0; sum = 0;
+					while (j < K && r > sum) sum += indiv ? st->mle_q[(size_t)i * K + j++] : st->mle_q[j++];
+					if (j) j--;
+				}
+				r = (double)mc_rand(&st->rng) / 2147483647.0;
+				int m = 0;
+				sum = 0;
+				while (m < d->uniquealleles[l] && r > sum) sum += st->mle_p[(size_t)j * T + d->toff[l] + m++];
+				if (m) m--;
+				geno[((size_t)i * d->L + l) * d->ploidy + n] = (uint8_t)m;
+			}
+	}
+}
+
+int main(int argc, const char **argv)
+{
+	mc_cli_options o;
+	mc_cli_data d;
+	run_state st;
+	int rc;
+	defaults(&o);
+	if ((rc = parse_options(&o, argc, argv))) return rc == 1 ? 0 : rc;
+	if ((rc = mc_read_structure(&o, &d))) return rc;
+	if (o.em.verbosity >= MC_TALKATIVE)
+		fprintf(stderr, "INFO: Finished reading data: %d %d-ploid individuals at %d loci.\n", d.I, d.ploidy, d.L);
+	mc_data md = { d.I, d.L, d.ploidy, d.uniquealleles, d.geno };
+	/* synchronize (multiclust.c:807-893) */
+	if (mc_synchronize(&o.em, &md)) return 2;
+	if (d.I < o.max_K) { fprintf(stderr, "ERROR: Maximum number of clusters (%d) (set with command-line argument -k) cannot exceed the number of individuals (%d)\n", o.max_K, d.I); return 2; }
+	if (o.n_bootstrap && o.max_K <= 1) { fprintf(stderr, "ERROR: When bootstrapping, maximum K (%d) (set with command-line argument -k) must exceed 1.\n", o.max_K); return 2; }
+	if (o.min_K > o.max_K) { fprintf(stderr, "ERROR: Minimum K (%d) must not exceed maximum K (%d).\n", o.min_K, o.max_K); return 2; }
+	if (!o.target_ll && !o.target_revisit && !o.em.n_seconds && !o.n_init) o.n_init = 1;
+	memset(&st, 0, sizeof st);
+	if (o.n_bootstrap) { st.null_K = o.max_K - 1; st.alt_K = o.max_K; }
+	/* the reference seeds libc only when -r is given; otherwise rand() runs from glibc's default seed 1 although the
+	 * banner prints 1234567 */
+	mc_srand(&st.rng, o.seed_given ? o.em.seed : 1u);
+
+	if (o.n_repeat > 1 || o.repeat_seconds) {	/* timed_model_estimation (multiclust.c:201-347) */
+		const clock_t start = clock();
+		double sum_ll = 0, sum_ll2 = 0, sum_init = 0, sum_iter = 0, max_ll = -INFINITY, esec = 0;
+		int n = 0, conv = 0, enough = o.repeat_seconds ? 0 : 1, total;
+		char ab[16];
+		while (n < o.n_repeat || !enough) {
+			if ((rc = estimate_model(&o, &d, &md, &st, 0, &total))) goto END;
+			if (st.sum.max_logL > max_ll) max_ll = st.sum.max_logL;
+			sum_ll += st.sum.max_logL; sum_ll2 += st.sum.max_logL * st.sum.max_logL;
+			sum_init += st.sum.n_init; sum_iter += st.sum.n_total_iter;
+			n++;
+			if (st.sum.ever_converged) conv++;
+			esec = ((double)clock() - start) / CLOCKS_PER_SEC;
+			if (o.em.verbosity > MC_SILENT) {
+				print_model_state(&o, &d, &st, o.max_K, (int)esec, 0);
+				printf(" %f %f %d %d %f NA %d %d %d %u\n", esec, esec / n, 0, conv, max_ll, o.target_revisit, n, o.n_repeat, o.repeat_seconds);
+			}
+			if (!enough && esec > o.repeat_seconds) enough = 1;
+			if (o.max_repeat_seconds && esec > o.max_repeat_seconds) break;
+		}
+		printf("Data, Method, Model: %s, %s, %s\n", o.filename, accel_abbrev(&o, ab),
+		       o.em.admixture && o.em.eta_constrained ? "admix constrained" : o.em.admixture ? "admix" : "mix");
+		printf("Number of repetitions: %d of %d requested, %d converged\n", n, o.n_repeat, conv);
+		printf("Average time: %fs (total: %fs; target: %u)\n", esec / n, esec, o.repeat_seconds);
+		printf("Average log likelihood: %f (+/- %f)\n", sum_ll / n, sqrt((sum_ll2 - sum_ll * sum_ll / n) / (n - 1)));
+		printf("Maximum log likelihood: %f\n", max_ll);
+		printf("Total initializations, iterations: %d, %d\n", (int)sum_init, (int)sum_iter);
+	} else if ((rc = estimate_model(&o, &d, &md, &st, 0, NULL))) {
+		goto END;
+	}
+	if (o.parallel) printf("%f\n", st.sum.max_logL);	/* multiclust.c:143-145 */
+
+	if (o.n_bootstrap) {	/* run_bootstrap (multiclust.c:675-708) */
+		uint8_t *orig = d.geno, *sim = malloc((size_t)d.I * d.L * d.ploidy);
+		int ntime = 0;
+		if (!sim || !st.mle_q) { rc = MCHIP_ERR_ALLOC; goto END; }
+		for (int b = 0; b < o.n_bootstrap; b++) {
+			printf("Bootstrap dataset %d (of %d):", b + 1, o.n_bootstrap);
+			bootstrap_genotypes(&o, &d, &st, sim);
+			md.geno = d.geno = sim;
+			rc = estimate_model(&o, &d, &md, &st, 1, NULL);
+			md.geno = d.geno = orig;
+			if (rc) { free(sim); goto END; }
+			if (st.ts_bs >= st.ts_obs) ntime++;
+			printf(" test statistics bs=%f obs=%f (%f)\n", st.ts_bs, st.ts_obs, (double)ntime / (b + 1));
+		}
+		free(sim);
+		/* the reference divides two ints here (multiclust.c:703); kept */
+		printf("p-value to reject H0: K=%d is %f\n", st.null_K, (double)(ntime / o.n_bootstrap));
+	}
+END:
+	free(st.mle_q); free(st.mle_p);
+	mc_free_data(&d);
+	return rc;
+}

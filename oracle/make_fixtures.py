@@ -79,6 +79,39 @@ def run(name, stru, n_em, snaps, n_cycles, args, keep_ilm=True):
             os.remove(os.path.join(out, fn))
 
 
+REFBIN = os.path.join(ROOT, "oracle", "_ref", "multiclust_ref")
+
+
+def run_cli(name, stru, args):
+    """The reference's own command line on a fixture: stdout and the five output files, kept as golden data."""
+    out = os.path.join(GOLD, "cli_" + name)
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    cmd = [REFBIN, "-f", stru, "-d", out] + args
+    print(" ".join(cmd))
+    res = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=out, text=True)
+    with open(os.path.join(out, "stdout.txt"), "w") as f:
+        f.write(res.stdout.replace(stru, os.path.basename(stru)))
+    with open(os.path.join(out, "ARGS.txt"), "w") as f:
+        f.write(" ".join(["-f", os.path.basename(stru)] + args) + "\n")
+
+
+def write_interleaved(src, dst, ploidy):
+    """Same data as `src` (ploidy consecutive lines per individual) as one interleaved line per individual, with the
+    optional inter-marker distance line the reader must skip (read_file.c:70-82, 100-116)."""
+    lines = open(src).read().strip().split("\n")
+    hdr, rows = lines[0], [l.split() for l in lines[1:]]
+    with open(dst, "w") as f:
+        f.write(hdr + "\n")
+        f.write("-1 " + " ".join("10" for _ in hdr.split()) + "\n")
+        for i in range(0, len(rows), ploidy):
+            grp = rows[i:i + ploidy]
+            vals = []
+            for l in range(len(grp[0]) - 2):
+                vals += [g[2 + l] for g in grp]
+            f.write("%s_%d %s " % (grp[0][0], i, grp[0][1]) + " ".join(vals) + "\n")
+
+
 def main():
     if not os.path.exists(HARNESS):
         sys.exit("build oracle/_ref/ref_harness first: make -C oracle ref")
@@ -110,6 +143,28 @@ def main():
     run("multi_mix_k3", multi, 10, "1,2,3,10", 3, ["-k", "3", "-r", "5", "-s", "3"])
     run("multi_admix_c_k3", multi, 10, "1,2,3,10", 3, ["-a", "-c", "-k", "3", "-r", "5", "-s", "3"])
     run("missing_mix_k2", miss, 5, "1,5", 0, ["-k", "2", "-r", "5"])
+
+    # reader-only fixtures: interleaved layout + "-1" line; remapped missing code
+    inter = os.path.join(data, "multi_interleaved.stru")
+    write_interleaved(multi, inter, 2)
+    run("reader_interleaved", inter, 1, "1", 0, ["-a", "-k", "2", "-r", "1"])
+    miss99 = os.path.join(data, "missing99.stru")
+    with open(miss) as fi, open(miss99, "w") as fo:
+        fo.write(fi.read().replace("-9", "99"))
+    run("reader_missing99", miss99, 1, "1", 0, ["-a", "-k", "2", "-r", "1", "--missing", "99"])
+    for name in ("reader_interleaved", "reader_missing99"):
+        d = os.path.join(GOLD, name)
+        for fn in os.listdir(d):
+            if fn not in ("manifest.json", "geno.u8", "uniquealleles.i32", "locale.i32", "ARGS.txt"):
+                os.remove(os.path.join(d, fn))
+
+    # the reference's own command line: stdout + output files
+    run_cli("multi_admix_k4", multi, ["-a", "-k", "4", "-r", "7", "-n", "3"])
+    run_cli("missing_admix_k3_s3", miss, ["-a", "-k", "3", "-r", "5", "-n", "2", "-s", "3"])
+    run_cli("multi_mix_k3", multi, ["-k", "3", "-r", "5", "-n", "2"])
+    run_cli("multi_admix_c_k3", multi, ["-a", "-c", "-k", "3", "-r", "5", "-n", "2"])
+    # (a K range, -1 <a> -2 <b>, aborts inside the reference itself after the first K: "free(): invalid pointer")
+    run_cli("tetra_admix_k3", tetra, ["-p", "4", "-a", "-k", "3", "-r", "11", "-n", "2"])
 
 
 if __name__ == "__main__":

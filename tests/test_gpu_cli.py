@@ -1,0 +1,105 @@
+"""-m gpu: the drop-in command line (multiclust_amd/bin/multiclust) end to end -- reader, initialisation from the
+libc-compatible stream, EM on the GPU, bookkeeping, stdout lines and the five output files -- against the
+reference's own binary run on the same files with the same arguments (tests/golden/cli_*)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from golden_util import GOLD
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "multiclust_amd", "bin", "multiclust")
+NUM = re.compile(r"-?\d+\.\d+(?:e[+-]?\d+)?|-?\d+")
+
+
+def run_cli(case, tmp_path, extra=()):
+    gdir = os.path.join(GOLD, "cli_" + case)
+    args = open(os.path.join(gdir, "ARGS.txt")).read().split()
+    stru = os.path.join(GOLD, "data", args[1])
+    cmd = [BIN, "-f", stru, "-d", str(tmp_path)] + args[2:] + list(extra)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    return gdir, res.stdout.replace(stru, os.path.basename(stru))
+
+
+def numeric_rows(path):
+    rows = []
+    for line in open(path):
+        toks = line.replace(":", " ").split()
+        rows.append(toks)
+    return rows
+
+
+def compare_file(ref, got, atol):
+    a, b = numeric_rows(ref), numeric_rows(got)
+    assert len(a) == len(b), (ref, len(a), len(b))
+    for ra, rb in zip(a, b):
+        assert len(ra) == len(rb), (ref, ra, rb)
+        for x, y in zip(ra, rb):
+            try:
+                fx, fy = float(x), float(y)
+            except ValueError:
+                assert x == y, (ref, ra, rb)
+                continue
+            assert abs(fx - fy) <= atol, (ref, ra, rb)
+
+
+@pytest.mark.parametrize("case,atol", [
+    ("multi_admix_k4", 2e-6),            # plain EM: same iteration counts, same 6-decimal files
+    ("multi_mix_k3", 2e-6),
+    ("multi_admix_c_k3", 2e-6),
+    ("tetra_admix_k3", 2e-6),
+    ("missing_admix_k3_s3", 5e-3),       # SQUAREM: the path may differ through accept ties; converged fit within tolerance
+])
+def test_cli_matches_reference_binary(case, atol, tmp_path):
+    gdir, out = run_cli(case, tmp_path)
+    ref_lines = open(os.path.join(gdir, "stdout.txt")).read().strip().split("\n")
+    got_lines = out.strip().split("\n")
+    assert len(ref_lines) == len(got_lines), out
+    exact = atol < 1e-4
+    for r, g in zip(ref_lines, got_lines):
+        rs, gs = NUM.sub("#", r), NUM.sub("#", g)
+        assert rs == gs, (r, g)                                      # same text skeleton, field for field
+        rn, gn = [float(x) for x in NUM.findall(r)], [float(x) for x in NUM.findall(g)]
+        for idx, (x, y) in enumerate(zip(rn, gn)):
+            if x == int(x) and abs(x) < 1e6 and "." not in NUM.findall(r)[idx]:
+                if exact:
+                    assert x == y, (r, g)                            # iteration counts, K, seed, bookkeeping
+            else:
+                assert abs(x - y) <= max(atol * 10, 1e-6 * abs(x)) + (0 if exact else 5e-2), (r, g)
+    files = sorted(f for f in os.listdir(gdir) if f not in ("stdout.txt", "ARGS.txt"))
+    assert len(files) == 5
+    for fn in files:
+        assert os.path.exists(tmp_path / fn), fn
+        compare_file(os.path.join(gdir, fn), tmp_path / fn, atol if not fn.endswith("out.txt") else max(atol * 10, 5e-2 if not exact else 1e-5))
+
+
+def test_cli_k_range_and_quiet_mode(tmp_path):
+    """-1/-2 K range (the reference itself aborts after the first K, so there is no golden: structural checks),
+    -M prints only the maximum log likelihood."""
+    stru = os.path.join(GOLD, "data", "multi.stru")
+    res = subprocess.run([BIN, "-f", stru, "-a", "-1", "2", "-2", "4", "-n", "2", "-r", "3", "-s", "3", "-d", str(tmp_path)],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.strip().split("\n")
+    assert len(lines) == 3 * (2 + 1)
+    lls = [float(l.split()[9]) for l in lines if l.startswith(stru)]
+    assert lls[0] < lls[1] < lls[2]                                    # more clusters fit better
+    for K in (2, 3, 4):
+        assert os.path.exists(tmp_path / ("multi.stru.admix.K=%d.pklm.txt" % K))
+    res = subprocess.run([BIN, "-f", stru, "-a", "-k", "2", "-n", "1", "-M", "-d", str(tmp_path)],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0 and len(res.stdout.strip().split("\n")) == 1
+    float(res.stdout.strip())
+
+
+def test_cli_bootstrap_runs(tmp_path):
+    stru = os.path.join(GOLD, "data", "multi.stru")
+    res = subprocess.run([BIN, "-f", stru, "-a", "-k", "2", "-n", "2", "-b", "2", "-r", "9", "-s", "3", "-d", str(tmp_path)],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    assert res.stdout.count("Bootstrap dataset") == 2 and "p-value to reject H0: K=1" in res.stdout

@@ -1,0 +1,95 @@
+"""CPU tests of the STRUCTURE reader (multiclust_amd/host/mc_reader.c) against what the reference's own reader
+produced for the same files (golden geno / uniquealleles / locale dumped by oracle/ref_harness.c)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import GOLD, Golden
+from multiclust_amd import host
+
+
+class CliOptions(C.Structure):
+    _fields_ = [("em", host.McOptions), ("filename", C.c_char_p), ("filename_file", C.c_char_p), ("path", C.c_char_p),
+                ("outfile_name", C.c_char_p), ("min_K", C.c_int), ("max_K", C.c_int), ("n_init", C.c_int),
+                ("n_bootstrap", C.c_int), ("n_rand_em_init", C.c_int), ("missing_value", C.c_int), ("R_format", C.c_int),
+                ("ploidy", C.c_int), ("seed_given", C.c_int), ("target_ll", C.c_int), ("target_revisit", C.c_int),
+                ("desired_ll", C.c_double), ("n_repeat", C.c_int), ("repeat_seconds", C.c_uint),
+                ("max_repeat_seconds", C.c_uint), ("write_files", C.c_int), ("compact", C.c_int), ("parallel", C.c_int),
+                ("device", C.c_int)]
+
+
+class CliData(C.Structure):
+    _fields_ = [("I", C.c_int), ("L", C.c_int), ("ploidy", C.c_int), ("M", C.c_int), ("missing_data", C.c_int),
+                ("interleaved", C.c_int), ("IL", C.POINTER(C.c_int)), ("uniquealleles", C.POINTER(C.c_int32)),
+                ("L_alleles", C.POINTER(C.POINTER(C.c_int))), ("geno", C.POINTER(C.c_uint8)),
+                ("names", C.POINTER(C.c_char_p)), ("locale", C.POINTER(C.c_int)), ("pops", C.POINTER(C.c_char_p)),
+                ("numpops", C.c_int), ("i_p", C.POINTER(C.c_int)), ("T", C.c_int), ("toff", C.POINTER(C.c_int32))]
+
+
+def read(path, ploidy=2, missing=-9, r_format=0):
+    lib = host.load()
+    lib.mc_read_structure.argtypes = [C.POINTER(CliOptions), C.POINTER(CliData)]
+    lib.mc_free_data.argtypes = [C.POINTER(CliData)]
+    o = CliOptions()
+    o.filename = path.encode()
+    o.ploidy, o.missing_value, o.R_format = ploidy, missing, r_format
+    d = CliData()
+    rc = lib.mc_read_structure(C.byref(o), C.byref(d))
+    if rc:
+        return rc, None
+    out = dict(I=d.I, L=d.L, ploidy=d.ploidy, T=d.T, M=d.M, missing_data=d.missing_data, interleaved=d.interleaved,
+               ua=np.ctypeslib.as_array(d.uniquealleles, shape=(d.L,)).copy(),
+               geno=np.ctypeslib.as_array(d.geno, shape=(d.I, d.L, d.ploidy)).copy(),
+               locale=np.ctypeslib.as_array(d.locale, shape=(d.I,)).copy(), numpops=d.numpops,
+               names=[d.names[i].decode() for i in range(d.I)], pops=[d.pops[i].decode() for i in range(d.numpops)],
+               i_p=[d.i_p[n] for n in range(d.numpops)])
+    lib.mc_free_data(C.byref(d))
+    return 0, out
+
+
+CASES = [("c1_admix_k3", "c1_tiny.stru", 2, -9), ("multi_admix_k4", "multi.stru", 2, -9),
+         ("tetra_admix_k3", "tetra.stru", 4, -9), ("missing_admix_k3", "missing.stru", 2, -9),
+         ("reader_interleaved", "multi_interleaved.stru", 2, -9), ("reader_missing99", "missing99.stru", 2, 99)]
+
+
+@pytest.mark.parametrize("gold,fn,ploidy,missing", CASES)
+def test_reader_matches_reference_reader(gold, fn, ploidy, missing):
+    g = Golden(gold)
+    rc, d = read(os.path.join(GOLD, "data", fn), ploidy=ploidy, missing=missing)
+    assert rc == 0
+    assert (d["I"], d["L"], d["ploidy"], d["T"], d["M"]) == (g.I, g.L, g.ploidy, g.T, g.m["M"])
+    assert d["missing_data"] == g.m["missing_data"] and d["numpops"] == g.m["numpops"]
+    assert np.array_equal(d["ua"], g.ua)
+    assert np.array_equal(d["geno"], g.geno)
+    assert np.array_equal(d["locale"], g.i32("locale.i32"))
+    assert sum(d["i_p"]) == g.I
+
+
+def test_interleaved_detection_and_names():
+    rc, a = read(os.path.join(GOLD, "data", "multi.stru"))
+    rc2, b = read(os.path.join(GOLD, "data", "multi_interleaved.stru"))
+    assert rc == 0 and rc2 == 0
+    assert a["interleaved"] == 0 and b["interleaved"] == 1
+    # with the "-1" line the reference's line count is one short (read_file.c:119): the last individual is dropped
+    assert a["I"] == 40 and b["I"] == 39
+    if np.array_equal(a["ua"], b["ua"]):
+        assert np.array_equal(a["geno"][:39], b["geno"])
+    assert a["names"][0] == "ind0" and a["pops"][:2] == ["pop0", "pop1"]
+
+
+def test_r_format_and_errors(tmp_path):
+    src = open(os.path.join(GOLD, "data", "multi.stru")).read().split("\n")
+    p = tmp_path / "r.stru"
+    p.write_text("name pop " + src[0] + "\n" + "\n".join(src[1:]))      # -R: header also names the two info columns
+    rc, d = read(str(p), r_format=1)
+    assert rc == 0 and d["L"] == 60
+    rc, _ = read(str(p), r_format=0)                                        # without -R the column counts disagree
+    assert rc != 0
+    rc, _ = read(str(tmp_path / "absent.stru"))
+    assert rc != 0
+    q = tmp_path / "odd.stru"
+    q.write_text("\n".join(src[:4]) + "\n")                                 # 3 haplotype lines: not a multiple of ploidy
+    rc, _ = read(str(q))
+    assert rc != 0
