@@ -93,8 +93,10 @@ def test_cli_k_range_and_quiet_mode(tmp_path):
         assert os.path.exists(tmp_path / ("multi.stru.admix.K=%d.pklm.txt" % K))
     res = subprocess.run([BIN, "-f", stru, "-a", "-k", "2", "-n", "1", "-M", "-d", str(tmp_path)],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
-    assert res.returncode == 0 and len(res.stdout.strip().split("\n")) == 1
-    float(res.stdout.strip())
+    # -M sets verbosity to SILENT (= 1, still non-zero), so the reference prints the summary line and then max_logL
+    out = res.stdout.strip().split("\n")
+    assert res.returncode == 0 and len(out) == 2
+    assert abs(float(out[1]) - float(out[0].split()[9])) < 1e-6
 
 
 def test_cli_bootstrap_runs(tmp_path):
