@@ -38,6 +38,20 @@ __device__ __forceinline__ double rcp_full(double t)
 	return __builtin_fma(r, p, r);
 }
 
+/* Four reciprocals from one: 1/(t0 t1 t2 t3) by rcp_full, then back-multiplication (9 multiplies + 1 reciprocal
+ * instead of 4 reciprocals; v_rcp_f64 issues at a quarter of the FMA rate).  Each t is in [p_lb/K, 1], so the
+ * product of four stays far from underflow; every result carries <= 2.5 ulp. */
+__device__ __forceinline__ void rcp4(const double (&t)[4], double (&rc)[4])
+{
+	const double p01 = t[0] * t[1], p23 = t[2] * t[3];
+	const double rp = rcp_full(p01 * p23);
+	const double r01 = rp * p23, r23 = rp * p01;
+	rc[0] = r01 * t[1];
+	rc[1] = r01 * t[0];
+	rc[2] = r23 * t[3];
+	rc[3] = r23 * t[2];
+}
+
 /* genotype bytes of sub-entry j (0..7) of an 8-entry group; PL = 2 fast path keeps the group in a uint4 */
 template <int PL> struct geno_group;
 
@@ -252,22 +266,28 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 			for (int h = 0; h < PERWORD / 4; h++) {
 				const int ibase = g * G + wi * PERWORD + h * 4;
 				if (ibase >= i1) break;		/* wave-uniform; padded individuals have zero counts anyway */
+				/* four individuals at a time: their q rows are wave-uniform (s_load_dwordx16 each) */
+				const double *__restrict__ q[4];
+				double n[4], t[4], rc[4];
 #pragma unroll
 				for (int j = 0; j < 4; j++) {
-					const int i = min(ibase + j, a.I - 1);
-					const double *__restrict__ q = a.Q + (size_t)i * a.qstride;	/* wave-uniform: s_load */
-					const double n = (double)((word >> (BITS * j)) & MASK);
-					double r;
-					if (MIX) {
-						r = n;
-					} else {
-						double t = q[0] * p[0];
+					q[j] = a.Q + (size_t)min(ibase + j, a.I - 1) * a.qstride;
+					n[j] = (double)((word >> (BITS * j)) & MASK);
+				}
+				if (!MIX) {
 #pragma unroll
-						for (int k = 1; k < K; k++) t = __builtin_fma(q[k], p[k], t);
-						r = n * rcp_full(t);
+					for (int j = 0; j < 4; j++) {
+						t[j] = q[j][0] * p[0];
+#pragma unroll
+						for (int k = 1; k < K; k++) t[j] = __builtin_fma(q[j][k], p[k], t[j]);
 					}
+					rcp4(t, rc);
+				}
 #pragma unroll
-					for (int k = 0; k < K; k++) acc[k] = __builtin_fma(q[k], r, acc[k]);
+				for (int j = 0; j < 4; j++) {
+					const double r = MIX ? n[j] : n[j] * rc[j];
+#pragma unroll
+					for (int k = 0; k < K; k++) acc[k] = __builtin_fma(q[j][k], r, acc[k]);
 				}
 				word >>= 4 * BITS;
 			}
@@ -399,37 +419,74 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_sparse(mchip_pass_args a)
 			const int l = lb * 8 + j;
 			if (l >= l1) break;			/* wave-uniform */
 			const int base = a.toff[l] - c_lo;
+			if constexpr (PL == 2 || PL == 4) {
+				/* all copies of the locus first (t), then one shared reciprocal for each pair of copies */
+				double pc[PL ? PL : 1][KP], t[PL ? PL : 1];
+				bool miss[PL ? PL : 1];
 #pragma unroll
-			for (int b = 0; b < (PL ? PL : 1); b++) {
-				for (int bb = 0; bb < (PL ? 1 : pl); bb++) {	/* generic ploidy: runtime loop over copies */
-					const unsigned mraw = g.copy(j, PL ? b : bb, pl);
+				for (int b = 0; b < PL; b++) {
+					const unsigned mraw = g.copy(j, b, pl);
 					/* NOMISS: the data set has no missing copy: no selects (idle lanes duplicate individual I-1) */
-					const bool miss = NOMISS ? false : ((mraw == MCHIP_MISSING) || !active);
-					const unsigned mm = miss ? 0u : mraw;
+					miss[b] = NOMISS ? false : ((mraw == MCHIP_MISSING) || !active);
+					const unsigned mm = miss[b] ? 0u : mraw;
 					/* 16-byte LDS reads (ds_read_b128): twice the bytes per LDS cycle of ds_read2_b64 */
 					const double2 *pr = reinterpret_cast<const double2 *>(tile + (size_t)(base + (int)mm) * KP);
-					double pc[KP];
 #pragma unroll
 					for (int k = 0; k < KP / 2; k++) {
 						const double2 v = pr[k];
-						pc[2 * k] = v.x;
-						pc[2 * k + 1] = v.y;
+						pc[b][2 * k] = v.x;
+						pc[b][2 * k + 1] = v.y;
 					}
-					double t = q[0] * pc[0];
+					t[b] = q[0] * pc[b][0];
 #pragma unroll
-					for (int k = 1; k < K; k++) t = __builtin_fma(q[k], pc[k], t);
+					for (int k = 1; k < K; k++) t[b] = __builtin_fma(q[k], pc[b][k], t[b]);
+				}
+#pragma unroll
+				for (int b = 0; b < PL; b += 2) {
+					const double pp = t[b] * t[b + 1];
 					if (ACCUM) {
-						const double rc = rcp_full(t);
-						const double r = miss ? 0.0 : rc;
+						const double rp = rcp_full(pp);
+						const double r0 = miss[b] ? 0.0 : rp * t[b + 1];
+						const double r1 = miss[b + 1] ? 0.0 : rp * t[b];
 #pragma unroll
-						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[k], r, acc[k]);
+						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b][k], r0, acc[k]);
+#pragma unroll
+						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b + 1][k], r1, acc[k]);
 					}
-					prod *= miss ? 1.0 : t;
+					if (NOMISS) {
+						prod *= pp;
+					} else {
+						prod *= miss[b] ? 1.0 : t[b];
+						prod *= miss[b + 1] ? 1.0 : t[b + 1];
+					}
 					if (SAFE) {
 						if (prod < 1e-100) {
 							ll += log(prod);
 							prod = 1.0;
 						}
+					}
+				}
+			} else {
+				for (int bb = 0; bb < pl; bb++) {	/* any other ploidy: one copy at a time */
+					const unsigned mraw = g.copy(j, bb, pl);
+					const bool miss = (mraw == MCHIP_MISSING) || !active;
+					const unsigned mm = miss ? 0u : mraw;
+					const double *pr = tile + (size_t)(base + (int)mm) * KP;
+					double pc[K];
+#pragma unroll
+					for (int k = 0; k < K; k++) pc[k] = pr[k];
+					double t = q[0] * pc[0];
+#pragma unroll
+					for (int k = 1; k < K; k++) t = __builtin_fma(q[k], pc[k], t);
+					if (ACCUM) {
+						const double r = miss ? 0.0 : rcp_full(t);
+#pragma unroll
+						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[k], r, acc[k]);
+					}
+					prod *= miss ? 1.0 : t;
+					if (prod < 1e-100) {
+						ll += log(prod);
+						prod = 1.0;
 					}
 				}
 			}

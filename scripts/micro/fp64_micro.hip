@@ -147,7 +147,7 @@ int main()
 	double *out;
 	CHK(hipMalloc(&out, sizeof(double) * cus * 8 * 512));
 	const int iters = 20000;
-	for (int wpc : {4, 8, 16}) {	// waves per CU
+	for (int wpc : {4, 8, 16, 20, 24, 32}) {	// waves per CU
 		dim3 grid(cus * wpc / 4), block(256);
 		double ms = time_ms([&] { hipLaunchKernelGGL(k_fma, grid, block, 0, 0, out, iters, 0.999, 0.001); });
 		double flops = (double)grid.x * 256 * iters * 16 * 2;
