@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6    # vector FP64 peak (spec), for the secondary fraction only
+FP64_VALU_MEASURED_TF = 70.5 # best v_fma_f64 rate measured on this chip (profiles/r01_fp64_microbench.txt)
 
 WORKLOADS = {
     # name: I, L, ploidy, max alleles, K, accel scheme, description
@@ -225,6 +226,13 @@ def main():
         ach = B[names[dom]] / (avg[dom] * 1e-3) / 1e9 if avg[dom] else 0.0
         nnz_flops = (5 * w["K"] + 5) * w["I"] * T          # SURVEY.md 8d, dense-over-columns upper bound
         value = total_iters / dt
+        # HBM traffic per launch of the dominant kernel: PMC FETCH_SIZE/WRITE_SIZE from separate `rocprofv3 --pmc` passes
+        # of this same command (scripts/summarize_profile.py; corrected as MI355X_MICROARCH.md prescribes), config 3 only
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_v2_c3_traffic.json")
+        if args.workload == "c3" and os.path.exists(tf):
+            want = "k_column_counts<2, false>" if dom == 0 else "k_individual_sparse<2, true, false, true>"
+            traffic = json.load(open(tf)).get(want, {}).get("hbm_bytes_per_launch_corrected")
         out = {
             "metric": "EM iterations/sec, IxLxK admixture",
             "value": value, "unit": "EM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -235,14 +243,16 @@ def main():
                        "em_iterations_per_step": iters_per_step, "units": "%d initialisation(s), one per GPU" % world,
                        "best_logL": float(best.item())},
             "roofline": {
-                "bound": "hbm", "kernel": "k_column_pass" if dom == 0 else "k_individual_sparse",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "bound": "hbm", "kernel": "k_column_counts (N-side sums)" if dom == 0 else "k_individual_sparse (S-side sums + logL)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": B[names[dom]], "avg_launch_ms": avg[dom],
                 "kernels_ms": {names[x]: avg[x] for x in range(hip.PROF_KINDS)},
                 "launches": {names[x]: kl[x] for x in range(hip.PROF_KINDS)},
                 "iteration_bytes": B["iteration"],
                 "iteration_hbm_frac": B["iteration"] * (value / world) / 1e9 / HBM_PEAK_GBS,
                 "fp64_valu_frac": nnz_flops * (value / world) / 1e12 / FP64_VALU_PEAK_TF,
+                "fp64_note": "kernels are FP64-issue-bound, not HBM-bound: (5K+5) flop per cell x I x T per iteration over the 78.6 TF/s "
+                             "vector-FP64 spec peak (best measured v_fma_f64 rate on this chip: %.1f TF/s)" % FP64_VALU_MEASURED_TF,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
