@@ -177,3 +177,81 @@ def test_mixture_vs_oracle_synthetic(ctx):
         close(ctx.get_p(0), mod.p(0), 1e-7, 1e-13)
         close(ctx.expected_counts(), mod.sik(), 1e-7, 1e-12)
     assert abs(ctx.loglik(0) - mod.loglik(0)) <= 1e-12 * abs(mod.logL) + 1e-8
+
+
+@pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,opts", [
+    (70, 150, 3, 2, 40, 0.0, {}),                                   # > 32 alleles at a locus: dense fallback kernels
+    (90, 210, 4, 1, 3, 0.02, {}),                                   # haploid
+    (50, 120, 3, 3, 4, 0.03, {}),                                   # triploid: generic copy loop, 2-bit counts
+    (40, 100, 2, 6, 5, 0.0, {}),                                    # hexaploid: generic copy loop, 4-bit counts
+    (130, 260, 5, 2, 3, 0.01, {"do_projection": 0}),                # projection off: per-copy log-product checks
+    (130, 260, 5, 2, 3, 0.0, {"lower_bound": 1e-40}),               # tiny lower bound: per-copy log-product checks
+    (100, 300, 16, 2, 4, 0.0, {}),                                  # K = MCHIP_MAX_K
+    (100, 300, 1, 2, 4, 0.0, {}),                                   # K = 1
+    (120, 240, 4, 2, 3, 0.02, {"eta_constrained": 1}),              # shared eta (-c)
+    (120, 240, 4, 4, 4, 0.02, {"eta_constrained": 1}),
+    (513, 64, 7, 2, 2, 0.0, {}),                                    # more individuals than a 512-wide tile, few loci
+    (9, 11, 2, 2, 2, 0.0, {}),                                      # tiny: fewer individuals / loci than any tile
+])
+def test_em_steps_vs_oracle_paths(ctx, I, L, K, ploidy, maxal, missing, opts):
+    """Every kernel variant (dense fallback, generic ploidy, safe log-product path, shared eta, K extremes)
+    against the oracle's fused-order restatement."""
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=7 * I + L, missing=missing)
+    user_lb = opts.get("lower_bound", 1e-8)
+    lb = ob.lib.mco_lower_bound(user_lb, I, ploidy)
+    q0, p0 = random_params(I, ua, K, seed=3, lower_bound=max(lb, 1e-12))
+    con = opts.get("eta_constrained", 0)
+    proj = opts.get("do_projection", 1)
+    if con:
+        q0 = q0[0].copy()
+    opt = ob.make_options(lower_bound=lb, fused=1, abs_error=0.0, eta_constrained=con, do_projection=proj)
+    mod = ob.Model(ob.Data(I, L, ploidy, ua, geno), opt, K)
+    mod.q(0)[...] = q0
+    mod.p(0)[...] = p0
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, eta_constrained=con, do_projection=proj, lower_bound=lb)
+    ctx.set_q(0, q0)
+    ctx.set_p(0, p0)
+    for s in range(1, 4):
+        mod.em_step()
+        ll = ctx.em_step(0, 0)
+        assert abs(ll - mod.logL) <= max(1e-8, 1e-12 * abs(mod.logL)), (s, ll, mod.logL)
+        rtol, atol = (1e-11, 1e-15) if s == 1 else (1e-8, 1e-13)
+        close(ctx.get_q(0), mod.q(0), rtol, atol)
+        close(ctx.get_p(0), mod.p(0), rtol, atol)
+        close(ctx.expected_counts(), mod.sik(), rtol, 1e-12)
+    assert abs(ctx.loglik(0) - mod.loglik(0)) <= max(1e-8, 1e-12 * abs(mod.logL))
+
+
+def test_accel_vector_ops_vs_numpy(ctx):
+    """mchip_secant / step_dots / secant_dots / accel_update against numpy on the fetched parameters."""
+    g = Golden("multi_admix_k4")
+    setup_case(ctx, g, n_secants=2)
+    ctx.em_step(0, 1)
+    ctx.em_step(1, 2)
+    x0q, x0p, x1q, x1p, x2q, x2p = ctx.get_q(0), ctx.get_p(0), ctx.get_q(1), ctx.get_p(1), ctx.get_q(2), ctx.get_p(2)
+    ctx.secant(0, 0, 1, 0)
+    ctx.secant(1, 0, 2, 1)
+    ctx.secant(0, 1, 2, 1)
+    ctx.secant(1, 1, 1, 0)
+    u = np.concatenate([(x1q - x0q).ravel(), (x1p - x0p).ravel()])
+    v = np.concatenate([(x2q - x1q).ravel(), (x2p - x1p).ravel()])
+    d = ctx.step_dots(0)
+    np.testing.assert_allclose(d, [u @ u, u @ (v - u), (v - u) @ (v - u)], rtol=1e-12)
+    d2 = ctx.secant_dots(0, 1)                     # u_0 . u_1 and u_0 . v_1, with u_1 = v, v_1 = u
+    np.testing.assert_allclose(d2, [u @ v, u @ u], rtol=1e-12)
+    s = -2.5
+    ctx.set_model  # (no-op reference to keep flake quiet)
+    lb = g.lower_bound
+    ctx.accel_update(2, 0, 0, s, 0)
+    want_q = x0q - 2 * s * (x1q - x0q) + s * s * ((x2q - x1q) - (x1q - x0q))
+    got_q = ctx.get_q(2)
+    for i in range(g.I):
+        np.testing.assert_allclose(got_q[i], ob.michelot(want_q[i], lb), rtol=1e-13, atol=1e-16)
+    want_p = x0p - 2 * s * (x1p - x0p) + s * s * ((x2p - x1p) - (x1p - x0p))
+    got_p = ctx.get_p(2)
+    off = 0
+    for M in g.ua:
+        for k in range(g.K):
+            np.testing.assert_allclose(got_p[k, off:off + M], ob.michelot(want_p[k, off:off + M], lb), rtol=1e-13, atol=1e-16)
+        off += M
