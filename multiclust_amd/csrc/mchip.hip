@@ -14,6 +14,8 @@
 #define DECL_KT(n) const mchip_ktable *mchip_ktable_get_##n();
 DECL_KT(1) DECL_KT(2) DECL_KT(3) DECL_KT(4) DECL_KT(5) DECL_KT(6) DECL_KT(7) DECL_KT(8)
 DECL_KT(9) DECL_KT(10) DECL_KT(11) DECL_KT(12) DECL_KT(13) DECL_KT(14) DECL_KT(15) DECL_KT(16)
+DECL_KT(17) DECL_KT(18) DECL_KT(19) DECL_KT(20) DECL_KT(21) DECL_KT(22) DECL_KT(23) DECL_KT(24)
+DECL_KT(25) DECL_KT(26) DECL_KT(27) DECL_KT(28) DECL_KT(29) DECL_KT(30) DECL_KT(31) DECL_KT(32)
 
 const mchip_ktable *mchip_get_ktable(int K)
 {
@@ -22,7 +24,10 @@ const mchip_ktable *mchip_get_ktable(int K)
 		nullptr, mchip_ktable_get_1, mchip_ktable_get_2, mchip_ktable_get_3, mchip_ktable_get_4, mchip_ktable_get_5,
 		mchip_ktable_get_6, mchip_ktable_get_7, mchip_ktable_get_8, mchip_ktable_get_9, mchip_ktable_get_10,
 		mchip_ktable_get_11, mchip_ktable_get_12, mchip_ktable_get_13, mchip_ktable_get_14, mchip_ktable_get_15,
-		mchip_ktable_get_16,
+		mchip_ktable_get_16, mchip_ktable_get_17, mchip_ktable_get_18, mchip_ktable_get_19, mchip_ktable_get_20,
+		mchip_ktable_get_21, mchip_ktable_get_22, mchip_ktable_get_23, mchip_ktable_get_24, mchip_ktable_get_25,
+		mchip_ktable_get_26, mchip_ktable_get_27, mchip_ktable_get_28, mchip_ktable_get_29, mchip_ktable_get_30,
+		mchip_ktable_get_31, mchip_ktable_get_32,
 	};
 	return (K >= 1 && K <= MCHIP_MAX_K) ? tabs[K]() : nullptr;
 }
@@ -623,7 +628,11 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	ctx->n_lchunks = (ctx->L + ctx->lchunk - 1) / ctx->lchunk;
 	ctx->n_ll_col = col_tiles * ctx->n_ichunks;
 	ctx->n_ll_ind = ind_tiles * ctx->n_lchunks;
-	ctx->sparse = (ctx->max_M <= MCHIP_SPARSE_MAX_M) && !getenv("MCHIP_FORCE_DENSE");
+	{	/* the sparse individual pass stages two tiles of 8 loci of P rows in LDS: use it while they fit 64 KiB */
+		const size_t kp = (size_t)((K + 1) & ~1);
+		const size_t lds = (2 * 8 * (size_t)ctx->max_M * kp + 128) * sizeof(double);
+		ctx->sparse = (ctx->max_M <= MCHIP_SPARSE_MAX_M) && lds <= 65536 && !getenv("MCHIP_FORCE_DENSE");
+	}
 	ctx->n_llpart = ctx->n_ll_col > ctx->n_ll_ind ? ctx->n_ll_col : ctx->n_ll_ind;
 	HIPCHK(hipMalloc((void **)&ctx->d_Apart, (size_t)ctx->n_ichunks * KT * sizeof(double)));
 	HIPCHK(hipMalloc((void **)&ctx->d_Spart, (size_t)ctx->n_lchunks * ctx->I * K * sizeof(double)));

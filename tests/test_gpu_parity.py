@@ -128,7 +128,7 @@ def test_invalid_inputs_are_rejected(ctx):
         ctx.set_genotypes(g.ua, bad)
     ctx.set_genotypes(g.ua, g.geno)
     with pytest.raises(mc.HipError):
-        ctx.set_model(17)                   # K > MCHIP_MAX_K
+        ctx.set_model(33)                   # K > MCHIP_MAX_K
     with pytest.raises(mc.HipError):
         ctx.set_model(0)
 
@@ -186,8 +186,10 @@ def test_mixture_vs_oracle_synthetic(ctx):
     (40, 100, 2, 6, 5, 0.0, {}),                                    # hexaploid: generic copy loop, 4-bit counts
     (130, 260, 5, 2, 3, 0.01, {"do_projection": 0}),                # projection off: per-copy log-product checks
     (130, 260, 5, 2, 3, 0.0, {"lower_bound": 1e-40}),               # tiny lower bound: per-copy log-product checks
-    (100, 300, 16, 2, 4, 0.0, {}),                                  # K = MCHIP_MAX_K
+    (100, 300, 16, 2, 4, 0.0, {}),                                  # K = 16 (largest tuned K)
     (100, 300, 1, 2, 4, 0.0, {}),                                   # K = 1
+    (80, 200, 23, 2, 4, 0.01, {}),                                  # K > 16: untuned but correct
+    (64, 128, 32, 4, 5, 0.0, {}),                                   # K = MCHIP_MAX_K, tetraploid
     (120, 240, 4, 2, 3, 0.02, {"eta_constrained": 1}),              # shared eta (-c)
     (120, 240, 4, 4, 4, 0.02, {"eta_constrained": 1}),
     (513, 64, 7, 2, 2, 0.0, {}),                                    # more individuals than a 512-wide tile, few loci
