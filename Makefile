@@ -22,9 +22,13 @@ $(OBJ)/mchip.o: multiclust_amd/csrc/mchip.hip multiclust_amd/csrc/mchip_internal
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIB)/libmulticlust_hip.so: $(OBJ)/mchip.o $(KOBJ)
+$(OBJ)/mchip_comm.o: multiclust_amd/csrc/mchip_comm.hip include/multiclust_hip.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB)/libmulticlust_hip.so: $(OBJ)/mchip.o $(OBJ)/mchip_comm.o $(KOBJ)
 	@mkdir -p $(LIB)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
 
 HOST_SRC = $(filter-out multiclust_amd/host/mc_main.c,$(wildcard multiclust_amd/host/*.c))
 $(LIB)/libmulticlust_host.so: $(HOST_SRC) $(wildcard multiclust_amd/host/*.h) include/multiclust_hip.h $(LIB)/libmulticlust_hip.so
@@ -34,7 +38,7 @@ $(LIB)/libmulticlust_host.so: $(HOST_SRC) $(wildcard multiclust_amd/host/*.h) in
 # the drop-in command line (same flags, reader and output files as the reference's `multiclust`)
 $(BIN)/multiclust: multiclust_amd/host/mc_main.c $(LIB)/libmulticlust_host.so
 	@mkdir -p $(BIN)
-	$(CC) $(CFLAGS) -Imulticlust_amd/host -o $@ $< -L$(LIB) -lmulticlust_host -lmulticlust_hip -Wl,-rpath,'$$ORIGIN/../lib' -lm
+	$(CC) $(CFLAGS) -Imulticlust_amd/host -o $@ $< -L$(LIB) -lmulticlust_host -lmulticlust_hip -Wl,-rpath,'$$ORIGIN/../lib' -lm -lpthread
 
 oracle:
 	$(MAKE) -C oracle all

@@ -144,14 +144,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # rehearsal knobs (not used by the driver): several ranks on ONE GPU need gloo and a shared device index
+    backend = os.environ.get("MC_BENCH_BACKEND", "nccl")
+    if "MC_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MC_BENCH_DEVICE"])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    cdev = dev if backend == "nccl" else torch.device("cpu")      # where the collective's tensors live
 
     from multiclust_amd import hip, host
     w = dict(WORKLOADS[args.workload])
@@ -200,7 +207,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    best = torch.tensor([fit.mod.logL], dtype=torch.float64, device=dev)
+    best = torch.tensor([fit.mod.logL], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(best, op=dist.ReduceOp.MAX)     # the path's one exchange: best log likelihood over units
     barrier()
@@ -210,8 +217,8 @@ def main():
     kl = (C.c_int * hip.PROF_KINDS)()
     hlib.mchip_profile_end(ctx, C.byref(total_ms), km, kl)
     n_iter = fit.mod.n_iter - n_iter0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    its = torch.tensor([float(n_iter)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    its = torch.tensor([float(n_iter)], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(its, op=dist.ReduceOp.SUM)

@@ -125,6 +125,19 @@ int mchip_accel_update(mchip_context *ctx, int to, int base, int j, double s, in
 int mchip_multisecant_update(mchip_context *ctx, int to, int base, int u_index, int n_terms,
 			     const int *v_index, const double *coef_a, const double *coef_b);
 
+/* ---- the path's one exchange step, for ONE process driving several GPUs ----
+ * Independent fits (random initialisations multiclust.c:516-653, bootstrap replicates 681-701) run one per context on
+ * different devices with no data-path collective; afterwards a single RCCL all-reduce over xGMI makes every device's
+ * copy of the per-unit result table complete (rows are disjoint: op 0 = sum) or picks the best log likelihood
+ * (op 1 = max).  host_bufs[d] is device d's table (count doubles), reduced in place.  RCCL is loaded lazily; without
+ * it mchip_comm_create returns MCHIP_ERR_UNSUPPORTED.  (One process per GPU, as bench.py runs, exchanges through
+ * torch.distributed instead.) */
+typedef struct mchip_comm mchip_comm;
+int mchip_comm_create(mchip_comm **comm, int n_devices, const int *devices);
+int mchip_comm_all_reduce(mchip_comm *comm, double *const *host_bufs, int count, int op);
+int mchip_comm_destroy(mchip_comm *comm);
+const char *mchip_comm_last_error(const mchip_comm *comm);
+
 /* ---- measurement hooks (bench.py): HIP events on the context's own stream ---- */
 int mchip_profile_begin(mchip_context *ctx);
 /* total_ms: begin..end on the stream.  kernel_ms[MCHIP_PROF_KINDS] / launches[MCHIP_PROF_KINDS]: summed

@@ -1,0 +1,148 @@
+/*
+ * mchip_comm.hip -- the path's one exchange step for a single process that drives several GPUs: an RCCL all-reduce
+ * of the per-unit result table.  RCCL is loaded lazily with dlopen, so that
+ * libmulticlust_hip.so has no link-time dependency on it (bench.py's processes already carry the RCCL that ships
+ * with PyTorch and exchange through torch.distributed instead).
+ */
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "multiclust_hip.h"
+
+struct mchip_comm {
+	int n;
+	std::vector<int> devices;
+	std::vector<ncclComm_t> comms;
+	std::vector<hipStream_t> streams;
+	std::vector<double *> dbuf;
+	size_t cap;		/* doubles per device buffer */
+	void *dl;
+	ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
+	ncclResult_t (*CommDestroy)(ncclComm_t);
+	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+	ncclResult_t (*GroupStart)(void);
+	ncclResult_t (*GroupEnd)(void);
+	const char *(*GetErrorString)(ncclResult_t);
+	char err[512];
+};
+
+static int cfail(mchip_comm *c, int code, const char *what, const char *detail)
+{
+	if (c) snprintf(c->err, sizeof c->err, "%s: %s", what, detail ? detail : "");
+	return code;
+}
+
+extern "C" {
+
+const char *mchip_comm_last_error(const mchip_comm *comm) { return comm ? comm->err : "null communicator"; }
+
+int mchip_comm_create(mchip_comm **out, int n_devices, const int *devices)
+{
+	if (!out || n_devices < 1 || !devices) return MCHIP_ERR_INVALID;
+	*out = nullptr;
+	int have = 0;
+	if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return MCHIP_ERR_NO_DEVICE;
+	for (int d = 0; d < n_devices; d++)
+		if (devices[d] < 0 || devices[d] >= have) return MCHIP_ERR_INVALID;
+	mchip_comm *c = new mchip_comm();
+	c->n = n_devices;
+	c->devices.assign(devices, devices + n_devices);
+	c->cap = 0;
+	c->err[0] = 0;
+	c->dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+	if (!c->dl) c->dl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+	if (!c->dl) {
+		fprintf(stderr, "mchip_comm_create: cannot load RCCL: %s\n", dlerror());
+		delete c;
+		return MCHIP_ERR_UNSUPPORTED;
+	}
+	*(void **)&c->CommInitAll = dlsym(c->dl, "ncclCommInitAll");
+	*(void **)&c->CommDestroy = dlsym(c->dl, "ncclCommDestroy");
+	*(void **)&c->AllReduce = dlsym(c->dl, "ncclAllReduce");
+	*(void **)&c->GroupStart = dlsym(c->dl, "ncclGroupStart");
+	*(void **)&c->GroupEnd = dlsym(c->dl, "ncclGroupEnd");
+	*(void **)&c->GetErrorString = dlsym(c->dl, "ncclGetErrorString");
+	if (!c->CommInitAll || !c->CommDestroy || !c->AllReduce || !c->GroupStart || !c->GroupEnd || !c->GetErrorString) {
+		fprintf(stderr, "mchip_comm_create: RCCL symbols missing\n");
+		dlclose(c->dl);
+		delete c;
+		return MCHIP_ERR_UNSUPPORTED;
+	}
+	c->comms.resize(n_devices);
+	/* RCCL prints a version banner on stdout at first initialisation; stdout belongs to the caller's result lines */
+	fflush(stdout);
+	const int saved = dup(1), devnull = open("/dev/null", O_WRONLY);
+	if (saved >= 0 && devnull >= 0) dup2(devnull, 1);
+	ncclResult_t r = c->CommInitAll(c->comms.data(), n_devices, devices);
+	fflush(stdout);
+	if (saved >= 0) { dup2(saved, 1); close(saved); }
+	if (devnull >= 0) close(devnull);
+	if (r != ncclSuccess) {
+		fprintf(stderr, "mchip_comm_create: ncclCommInitAll failed: %s\n", c->GetErrorString(r));
+		dlclose(c->dl);
+		delete c;
+		return MCHIP_ERR_HIP;
+	}
+	c->streams.resize(n_devices);
+	c->dbuf.assign(n_devices, nullptr);
+	for (int d = 0; d < n_devices; d++) {
+		if (hipSetDevice(devices[d]) != hipSuccess || hipStreamCreateWithFlags(&c->streams[d], hipStreamNonBlocking) != hipSuccess) {
+			delete c;
+			return MCHIP_ERR_HIP;
+		}
+	}
+	*out = c;
+	return MCHIP_OK;
+}
+
+int mchip_comm_all_reduce(mchip_comm *c, double *const *host_bufs, int count, int op)
+{
+	if (!c || !host_bufs || count <= 0 || (op != 0 && op != 1)) return MCHIP_ERR_INVALID;
+	if ((size_t)count > c->cap) {
+		for (int d = 0; d < c->n; d++) {
+			if (hipSetDevice(c->devices[d]) != hipSuccess) return cfail(c, MCHIP_ERR_HIP, "hipSetDevice", "");
+			if (c->dbuf[d]) (void)hipFree(c->dbuf[d]);
+			if (hipMalloc((void **)&c->dbuf[d], sizeof(double) * (size_t)count) != hipSuccess) return cfail(c, MCHIP_ERR_ALLOC, "hipMalloc", "");
+		}
+		c->cap = (size_t)count;
+	}
+	for (int d = 0; d < c->n; d++) {
+		if (hipSetDevice(c->devices[d]) != hipSuccess ||
+		    hipMemcpyAsync(c->dbuf[d], host_bufs[d], sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->streams[d]) != hipSuccess)
+			return cfail(c, MCHIP_ERR_HIP, "upload", "");
+	}
+	ncclResult_t r = c->GroupStart();
+	for (int d = 0; d < c->n && r == ncclSuccess; d++)
+		r = c->AllReduce(c->dbuf[d], c->dbuf[d], (size_t)count, ncclFloat64, op ? ncclMax : ncclSum, c->comms[d], c->streams[d]);
+	if (r == ncclSuccess) r = c->GroupEnd();
+	if (r != ncclSuccess) return cfail(c, MCHIP_ERR_HIP, "ncclAllReduce", c->GetErrorString(r));
+	for (int d = 0; d < c->n; d++) {
+		if (hipSetDevice(c->devices[d]) != hipSuccess ||
+		    hipMemcpyAsync(host_bufs[d], c->dbuf[d], sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->streams[d]) != hipSuccess ||
+		    hipStreamSynchronize(c->streams[d]) != hipSuccess)
+			return cfail(c, MCHIP_ERR_HIP, "download", "");
+	}
+	return MCHIP_OK;
+}
+
+int mchip_comm_destroy(mchip_comm *c)
+{
+	if (!c) return MCHIP_OK;
+	for (int d = 0; d < c->n; d++) {
+		(void)hipSetDevice(c->devices[d]);
+		if (c->dbuf[d]) (void)hipFree(c->dbuf[d]);
+		if (d < (int)c->streams.size()) (void)hipStreamDestroy(c->streams[d]);
+		if (d < (int)c->comms.size() && c->comms[d]) (void)c->CommDestroy(c->comms[d]);
+	}
+	if (c->dl) dlclose(c->dl);
+	delete c;
+	return MCHIP_OK;
+}
+
+}  /* extern "C" */

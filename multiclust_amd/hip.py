@@ -60,6 +60,10 @@ def load():
         "mchip_profile_begin": ([vp], i32),
         "mchip_profile_end": ([vp, dp, dp, ip], i32),
         "mchip_device_info": ([vp, C.c_char_p, i32, ip, dp], i32),
+        "mchip_comm_create": ([C.POINTER(vp), i32, ip], i32),
+        "mchip_comm_all_reduce": ([vp, C.POINTER(dp), i32, i32], i32),
+        "mchip_comm_destroy": ([vp], i32),
+        "mchip_comm_last_error": ([vp], C.c_char_p),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)        # AttributeError here = the library does not export its own header
@@ -75,7 +79,8 @@ ABI_SYMBOLS = [
     "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_last_loglik", "mchip_e_step",
     "mchip_loglik", "mchip_mstep_from_partition", "mchip_get_expected_counts", "mchip_secant", "mchip_step_dots",
     "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
-    "mchip_profile_end", "mchip_device_info",
+    "mchip_profile_end", "mchip_device_info", "mchip_comm_create", "mchip_comm_all_reduce", "mchip_comm_destroy",
+    "mchip_comm_last_error",
 ]
 
 

@@ -39,7 +39,8 @@ class McRng(C.Structure):
 
 class McUnitResult(C.Structure):
     _fields_ = [("unit", C.c_int), ("logL", C.c_double), ("converged", C.c_int), ("n_iter", C.c_int),
-                ("time_stop", C.c_int), ("iter_stop", C.c_int), ("pindex", C.c_int), ("fatal", C.c_int)]
+                ("time_stop", C.c_int), ("iter_stop", C.c_int), ("pindex", C.c_int), ("fatal", C.c_int),
+                ("seconds_run", C.c_double)]
 
 
 class McSummary(C.Structure):

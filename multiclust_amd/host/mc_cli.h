@@ -34,6 +34,7 @@ typedef struct mc_cli_options {
 	int compact;
 	int parallel;			/* -M */
 	int device;			/* --device (extension): HIP device index */
+	int n_gpus;			/* --gpus (extension): shard initialisations over devices device..device+n_gpus-1 */
 } mc_cli_options;
 
 typedef struct mc_cli_data {

@@ -119,5 +119,6 @@ int mc_fit_unit(const mc_options *opt, const mc_data *dat, mc_model *mod, unsign
 	out->iter_stop = mod->iter_stop;
 	out->pindex = mod->pindex;
 	out->fatal = mod->fatal;
+	out->seconds_run = mod->seconds_run;
 	return 0;
 }

@@ -117,6 +117,7 @@ typedef struct mc_unit_result {	/* what one initialisation + em() leaves behind 
 	int unit;
 	double logL;
 	int converged, n_iter, time_stop, iter_stop, pindex, fatal;
+	double seconds_run;	/* CPU seconds since the model's start stamp when the fit stopped (em_alg.c:147) */
 } mc_unit_result;
 
 typedef struct mc_summary {	/* state maintained across initialisations (multiclust.h:337-353) */

@@ -8,12 +8,16 @@
  * (618-627), print_model_state (718-793), run_bootstrap (675-708) and the -w repetition summary (201-347).
  * Deliberately absent (documented in DESIGN.md): -I/-I1 (allele-index mode gives different numbers from default
  * mode in the reference itself), --impute, --simulate, -x (not implemented in the reference either), -A, -P/-Q.
- * Extension: --device <n> selects the HIP device.
+ * Extensions: --device <n> selects the HIP device; --gpus <n> shards the initialisations of each K over n GPUs of
+ * the node (one host thread and one context per GPU, units u = d, d+n, ..., each starting from the serial program's
+ * rand() position by jump-ahead), with a single RCCL all-reduce of the per-unit result table, after which the serial
+ * bookkeeping is replayed in unit order (admixture model, fixed number of initialisations).
  */
 #include "mc_cli.h"
 
 #include <errno.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -40,7 +44,8 @@ static void usage(FILE *fp, const char *prog)
 		"  -w n <n> | t <min> | m <min>   repeat the fit for timing (no files written)\n"
 		"  -d <dir> -o <stem>  output directory / file stem      -R  R-formatted STRUCTURE file\n"
 		"  --missing <n> missing-data code (default -9)           -M  print only the maximum log likelihood\n"
-		"  -v [level]    verbosity                                --device <n>  HIP device index\n", prog);
+		"  -v [level]    verbosity                                --device <n>  HIP device index\n"
+		"  --gpus <n>    shard the initialisations over n GPUs (admixture; one RCCL all-reduce of the results)\n", prog);
 }
 
 static int arg_int(int argc, const char **argv, int i, long *out)
@@ -73,6 +78,7 @@ static void defaults(mc_cli_options *o)
 	o->n_repeat = 1;
 	o->write_files = 1;
 	o->compact = 1;
+	o->n_gpus = 1;
 }
 
 #define BAD(msg) do { fprintf(stderr, "ERROR [mc_main.c::parse_options]: %s (argument '%s'); try -h\n", msg, i < argc ? argv[i] : ""); return 2; } while (0)
@@ -107,7 +113,10 @@ static int parse_options(mc_cli_options *o, int argc, const char **argv)
 			for (size_t x = strlen(o->filename); x-- > 1;)
 				if (o->filename[x] == '/') { o->filename_file = &o->filename[x + 1]; break; }
 			break;
-		case 'g': if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-g"); o->em.adjust_step = (int)v; break;
+		case 'g':
+			if (!strncmp(w, "gp", 2)) { if (arg_int(argc, argv, ++i, &v) || v < 1 || v > 64) BAD("--gpus"); o->n_gpus = (int)v; }
+			else { if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-g"); o->em.adjust_step = (int)v; }
+			break;
 		case 'h': usage(stdout, argv[0]); return 1;
 		case 'i':
 			if (!strncmp(w, "im", 2)) BAD("--impute is not supported by this build");
@@ -234,7 +243,7 @@ static int maximize_likelihood(const mc_cli_options *o, const mc_cli_data *d, co
 		mc_em(&o->em, md, mod);
 		if (mod->fatal == MC_FATAL_DEVICE) { rc = MCHIP_ERR_HIP; goto DONE; }
 		if (mod->fatal) exit(0);		/* the reference's reaction to NaN / decreasing logL (em_alg.c:106-120) */
-		mc_unit_result r = { i, mod->logL, mod->converged, mod->n_iter, mod->time_stop, mod->iter_stop, mod->pindex, 0 };
+		mc_unit_result r = { i, mod->logL, mod->converged, mod->n_iter, mod->time_stop, mod->iter_stop, mod->pindex, 0, mod->seconds_run };
 		const double prev_max = st->sum.max_logL;
 		mc_summary_add(&o->em, &st->sum, &r, npar, d->I);
 		if (mod->logL > prev_max) {
@@ -281,6 +290,146 @@ DONE:
 	return rc;
 }
 
+
+/* ---- initialisations sharded over several GPUs of the node ---- */
+typedef struct shard_worker {
+	const mc_cli_options *o;
+	const mc_cli_data *d;
+	const mc_data *md;
+	int K, index, n_dev, n_units, want_params;
+	mc_rng base;			/* the serial stream's state where this K's initialisations begin */
+	uint64_t draws;
+	mc_unit_result *res;		/* [n_units], shared: worker d writes rows u = d, d + n_dev, ... */
+	double best_logL;
+	int best_unit, rc;
+	double *q, *p, *sik;		/* parameters of this worker's best unit */
+} shard_worker;
+
+static void *shard_main(void *arg)
+{
+	shard_worker *w = arg;
+	const int nq = (w->o->em.admixture && !w->o->em.eta_constrained) ? w->d->I * w->K : w->K;
+	mc_model *mod = NULL;
+	w->best_logL = -INFINITY;
+	w->best_unit = -1;
+	if ((w->rc = mc_model_create(&mod, &w->o->em, w->md, w->K, w->o->device + w->index))) return NULL;
+	const clock_t start = clock();
+	for (int u = w->index; u < w->n_units; u += w->n_dev) {
+		mc_rng rng = w->base;
+		mc_rng_jump(&rng, (uint64_t)u * w->draws);
+		mc_reset_model_state(mod);
+		mod->start = start;
+		if ((w->rc = mc_initialize_model(&w->o->em, w->md, mod, &rng))) break;
+		mc_em(&w->o->em, w->md, mod);
+		if (mod->fatal == MC_FATAL_DEVICE) { w->rc = MCHIP_ERR_HIP; break; }
+		mc_unit_result *r = &w->res[u];
+		r->unit = u; r->logL = mod->logL; r->converged = mod->converged; r->n_iter = mod->n_iter;
+		r->time_stop = mod->time_stop; r->iter_stop = mod->iter_stop; r->pindex = mod->pindex; r->fatal = mod->fatal;
+		r->seconds_run = mod->seconds_run;
+		if (mod->fatal) break;
+		if (w->want_params && mod->logL > w->best_logL) {	/* strict: the earliest of equal units wins, as in the serial loop */
+			if (!w->q) { w->q = malloc(sizeof(double) * (size_t)nq); w->p = malloc(sizeof(double) * (size_t)w->K * w->d->T);
+				     w->sik = malloc(sizeof(double) * (size_t)w->d->I * w->K); }
+			if (!w->q || !w->p || !w->sik) { w->rc = MCHIP_ERR_ALLOC; break; }
+			if ((w->rc = mc_model_get_q(mod, mod->pindex, w->q)) || (w->rc = mc_model_get_p(mod, mod->pindex, w->p)) ||
+			    (w->rc = mc_model_get_expected_counts(mod, w->sik))) break;
+			w->best_logL = mod->logL;
+			w->best_unit = u;
+		}
+	}
+	mc_model_free(mod);
+	return NULL;
+}
+
+#define RES_FIELDS 9
+static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, int K, run_state *st, int bootstrap)
+{
+	const int n_dev = o->n_gpus, n_units = (K == 1) ? 1 : o->n_init;
+	const int nq = (o->em.admixture && !o->em.eta_constrained) ? d->I * K : K;
+	const int npar = mc_no_parameters(&o->em, md, K);
+	const int keep_mle = !bootstrap && o->n_bootstrap && K == st->null_K;
+	const double max_logL_keep = st->sum.max_logL;
+	shard_worker *w = calloc((size_t)n_dev, sizeof *w);
+	pthread_t *th = calloc((size_t)n_dev, sizeof *th);
+	mc_unit_result *res = calloc((size_t)n_units, sizeof *res);
+	double **tab = calloc((size_t)n_dev, sizeof *tab);
+	int *devs = calloc((size_t)n_dev, sizeof *devs), *count_K = calloc((size_t)K, sizeof *count_K), rc = 0;
+	mchip_comm *comm = NULL;
+	if (!w || !th || !res || !tab || !devs || !count_K) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+	for (int x = 0; x < n_dev; x++) {
+		w[x].o = o; w[x].d = d; w[x].md = md; w[x].K = K; w[x].index = x; w[x].n_dev = n_dev; w[x].n_units = n_units;
+		w[x].want_params = keep_mle || (!bootstrap && o->write_files);
+		w[x].base = st->rng; w[x].draws = mc_draws_per_init(&o->em, md, K); w[x].res = res;
+		devs[x] = o->device + x;
+		if (pthread_create(&th[x], NULL, shard_main, &w[x])) { rc = MCHIP_ERR_ALLOC; n_units ? (void)0 : (void)0; }
+	}
+	for (int x = 0; x < n_dev; x++) pthread_join(th[x], NULL);
+	for (int x = 0; x < n_dev; x++) if (w[x].rc) rc = w[x].rc;
+	if (rc) goto DONE;
+	mc_rng_jump(&st->rng, (uint64_t)n_units * w[0].draws);	/* where the serial stream stands after these initialisations */
+
+	/* the one exchange: every device's result table holds its own rows; an RCCL all-reduce (sum) completes them all */
+	for (int x = 0; x < n_dev; x++) {
+		if (!(tab[x] = calloc((size_t)n_units * RES_FIELDS, sizeof(double)))) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+		for (int u = x; u < n_units; u += n_dev) {
+			double *row = tab[x] + (size_t)u * RES_FIELDS;
+			row[0] = res[u].logL; row[1] = res[u].converged; row[2] = res[u].n_iter; row[3] = res[u].time_stop;
+			row[4] = res[u].iter_stop; row[5] = res[u].pindex; row[6] = res[u].fatal; row[7] = res[u].seconds_run; row[8] = 1.0;
+		}
+	}
+	if ((rc = mchip_comm_create(&comm, n_dev, devs))) { fprintf(stderr, "ERROR [mc_main.c]: cannot create the RCCL communicator (status %d)\n", rc); goto DONE; }
+	if ((rc = mchip_comm_all_reduce(comm, tab, n_units * RES_FIELDS, 0))) { fprintf(stderr, "ERROR [mc_main.c]: %s\n", mchip_comm_last_error(comm)); goto DONE; }
+	for (int x = 1; x < n_dev; x++)
+		if (memcmp(tab[0], tab[x], sizeof(double) * (size_t)n_units * RES_FIELDS)) { fprintf(stderr, "ERROR [mc_main.c]: devices disagree after the all-reduce\n"); rc = MCHIP_ERR_STATE; goto DONE; }
+
+	/* replay the serial bookkeeping in unit order (multiclust.c:534-560, 618-627) */
+	mc_summary_reset(&st->sum);
+	st->sum.max_logL = max_logL_keep;
+	st->time_stop = 0;
+	for (int u = 0; u < n_units; u++) {
+		const double *row = tab[0] + (size_t)u * RES_FIELDS;
+		if (row[8] != 1.0) { fprintf(stderr, "ERROR [mc_main.c]: unit %d was fitted %g times\n", u, row[8]); rc = MCHIP_ERR_STATE; goto DONE; }
+		if ((int)row[6]) exit(0);		/* NaN / decreasing logL: the reference's reaction (em_alg.c:106-120) */
+		mc_unit_result r = { u, row[0], (int)row[1], (int)row[2], (int)row[3], (int)row[4], (int)row[5], 0, row[7] };
+		mc_summary_add(&o->em, &st->sum, &r, npar, d->I);
+		if (!bootstrap && o->em.verbosity > MC_QUIET && o->write_files)
+			printf("K = %d, initialization = %d: %f (%s) in %3d iterations, %02d:%02d:%02d (%f; %d), seed: %u\n", K, u, r.logL,
+			       r.converged ? "converged" : "not converged", r.n_iter, (int)(r.seconds_run / 3600),
+			       (int)((((int)r.seconds_run) % 3600) / 60), ((int)r.seconds_run) % 60, st->sum.max_logL, st->sum.n_maxll_times, o->em.seed);
+	}
+	/* the winner's parameters live on the device that fitted it */
+	if (st->sum.best_unit >= 0 && (keep_mle || (!bootstrap && o->write_files))) {
+		const shard_worker *own = &w[st->sum.best_unit % n_dev];
+		if (own->best_unit != st->sum.best_unit) { fprintf(stderr, "ERROR [mc_main.c]: owner of the best unit does not hold it\n"); rc = MCHIP_ERR_STATE; goto DONE; }
+		if (keep_mle) {
+			free(st->mle_q); free(st->mle_p);
+			st->mle_q = malloc(sizeof(double) * (size_t)nq); st->mle_p = malloc(sizeof(double) * (size_t)K * d->T);
+			memcpy(st->mle_q, own->q, sizeof(double) * (size_t)nq);
+			memcpy(st->mle_p, own->p, sizeof(double) * (size_t)K * d->T);
+			st->mle_K = K;
+		}
+		if (!bootstrap && o->write_files) {
+			mc_fit_view fv = { K, res[st->sum.best_unit].converged, st->sum.max_logL, st->sum.aic, st->sum.bic, own->q, own->p, own->sik };
+			mc_partition(d, &fv, NULL, count_K);
+			rc = mc_write_results(o, d, &fv, count_K);
+		}
+	}
+DONE:
+	if (comm) mchip_comm_destroy(comm);
+	if (w) for (int x = 0; x < n_dev; x++) { free(w[x].q); free(w[x].p); free(w[x].sik); }
+	if (tab) for (int x = 0; x < n_dev; x++) free(tab[x]);
+	free(w); free(th); free(res); free(tab); free(devs); free(count_K);
+	return rc;
+}
+
+static int shardable(const mc_cli_options *o)
+{
+	/* MC_FORCE_SHARDED=1 sends even --gpus 1 through the sharded path (threads, jump-ahead, RCCL exchange, replay): the
+	 * single-GPU rehearsal used by tests/test_gpu_cli.py */
+	const int force = getenv("MC_FORCE_SHARDED") != NULL;
+	return (o->n_gpus > 1 || force) && o->em.admixture && !o->target_revisit && !o->target_ll && !o->em.n_seconds;
+}
+
 /* estimate_model (multiclust.c:365-452): K = min_K..max_K, or H0 / HA when bootstrapping */
 static int estimate_model(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, run_state *st, int bootstrap, int *total_iter)
 {
@@ -291,10 +440,14 @@ static int estimate_model(const mc_cli_options *o, const mc_cli_data *d, const m
 	st->max_logL_H0 = -INFINITY;
 	if (total_iter) *total_iter = 0;
 	for (;;) {
-		mc_model *mod = NULL;
-		if ((rc = mc_model_create(&mod, &o->em, md, K, o->device))) return rc;
-		rc = maximize_likelihood(o, d, md, mod, st, bootstrap);
-		mc_model_free(mod);
+		if (shardable(o)) {
+			rc = maximize_likelihood_sharded(o, d, md, K, st, bootstrap);
+		} else {
+			mc_model *mod = NULL;
+			if ((rc = mc_model_create(&mod, &o->em, md, K, o->device))) return rc;
+			rc = maximize_likelihood(o, d, md, mod, st, bootstrap);
+			mc_model_free(mod);
+		}
 		if (rc) return rc;
 		if (o->n_repeat == 1 && o->em.verbosity)
 			print_model_state(o, d, st, K, (int)(((double)clock() - start) / CLOCKS_PER_SEC), 1);
@@ -374,6 +527,8 @@ int main(int argc, const char **argv)
 	/* the reference seeds libc only when -r is given; otherwise rand() runs from glibc's default seed 1 although the
 	 * banner prints 1234567 */
 	mc_srand(&st.rng, o.seed_given ? o.em.seed : 1u);
+	if (o.n_gpus > 1 && !shardable(&o))
+		fprintf(stderr, "WARNING: --gpus applies to the admixture model with a fixed number of initialisations; running on one GPU\n");
 
 	if (o.n_repeat > 1 || o.repeat_seconds) {	/* timed_model_estimation (multiclust.c:201-347) */
 		const clock_t start = clock();

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "multiclust_amd", "bin", "multiclust")
 NUM = re.compile(r"-?\d+\.\d+(?:e[+-]?\d+)?|-?\d+")
+CLOCK = re.compile(r"\d\d:\d\d:\d\d")       # elapsed CPU time: not comparable between machines
 
 
 def run_cli(case, tmp_path, extra=()):
@@ -23,7 +24,7 @@ def run_cli(case, tmp_path, extra=()):
     cmd = [BIN, "-f", stru, "-d", str(tmp_path)] + args[2:] + list(extra)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
-    return gdir, res.stdout.replace(stru, os.path.basename(stru))
+    return gdir, CLOCK.sub("HH:MM:SS", res.stdout.replace(stru, os.path.basename(stru)))
 
 
 def numeric_rows(path):
@@ -57,7 +58,7 @@ def compare_file(ref, got, atol):
 ])
 def test_cli_matches_reference_binary(case, atol, tmp_path):
     gdir, out = run_cli(case, tmp_path)
-    ref_lines = open(os.path.join(gdir, "stdout.txt")).read().strip().split("\n")
+    ref_lines = CLOCK.sub("HH:MM:SS", open(os.path.join(gdir, "stdout.txt")).read()).strip().split("\n")
     got_lines = out.strip().split("\n")
     assert len(ref_lines) == len(got_lines), out
     exact = atol < 1e-4
@@ -105,3 +106,22 @@ def test_cli_bootstrap_runs(tmp_path):
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr
     assert res.stdout.count("Bootstrap dataset") == 2 and "p-value to reject H0: K=1" in res.stdout
+
+
+@pytest.mark.parametrize("case", ["multi_admix_k4", "tetra_admix_k3"])
+def test_cli_sharded_path_on_one_gpu_reproduces_serial_reference(case, tmp_path, monkeypatch):
+    """The --gpus machinery (host thread per device, unit = initialisation, rand() jump-ahead, RCCL all-reduce of the
+    result table, serial-order bookkeeping replay, winner's owner writes the files) rehearsed with one device:
+    stdout and files must equal the reference's serial run."""
+    monkeypatch.setenv("MC_FORCE_SHARDED", "1")
+    gdir, out = run_cli(case, tmp_path, extra=["--gpus", "1"])
+    ref_lines = CLOCK.sub("HH:MM:SS", open(os.path.join(gdir, "stdout.txt")).read()).strip().split("\n")
+    got_lines = out.strip().split("\n")
+    assert len(ref_lines) == len(got_lines), out
+    for r, g in zip(ref_lines, got_lines):
+        assert NUM.sub("#", r) == NUM.sub("#", g), (r, g)
+        rn, gn = [float(x) for x in NUM.findall(r)], [float(x) for x in NUM.findall(g)]
+        for x, y in zip(rn, gn):
+            assert abs(x - y) <= 2e-5 + 1e-9 * abs(x), (r, g)
+    for fn in sorted(f for f in os.listdir(gdir) if f not in ("stdout.txt", "ARGS.txt")):
+        compare_file(os.path.join(gdir, fn), tmp_path / fn, 2e-5)

@@ -17,7 +17,7 @@ class CliOptions(C.Structure):
                 ("ploidy", C.c_int), ("seed_given", C.c_int), ("target_ll", C.c_int), ("target_revisit", C.c_int),
                 ("desired_ll", C.c_double), ("n_repeat", C.c_int), ("repeat_seconds", C.c_uint),
                 ("max_repeat_seconds", C.c_uint), ("write_files", C.c_int), ("compact", C.c_int), ("parallel", C.c_int),
-                ("device", C.c_int)]
+                ("device", C.c_int), ("n_gpus", C.c_int)]
 
 
 class CliData(C.Structure):
