@@ -3,7 +3,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 CC      ?= gcc
 ARCH    ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Imulticlust_amd/csrc -Wall -Wno-unused-function
-CFLAGS   = -std=c11 -O2 -fPIC -Wall -Wextra -Iinclude
+CFLAGS   = -std=gnu11 -O2 -fPIC -Wall -Wextra -Iinclude
 
 OBJ  = build/obj
 LIB  = multiclust_amd/lib
@@ -33,7 +33,7 @@ $(LIB)/libmulticlust_hip.so: $(OBJ)/mchip.o $(OBJ)/mchip_comm.o $(KOBJ)
 HOST_SRC = $(filter-out multiclust_amd/host/mc_main.c,$(wildcard multiclust_amd/host/*.c))
 $(LIB)/libmulticlust_host.so: $(HOST_SRC) $(wildcard multiclust_amd/host/*.h) include/multiclust_hip.h $(LIB)/libmulticlust_hip.so
 	@mkdir -p $(LIB)
-	$(CC) $(CFLAGS) -Imulticlust_amd/host -shared -o $@ $(HOST_SRC) -L$(LIB) -lmulticlust_hip -Wl,-rpath,'$$ORIGIN' -lm
+	$(CC) $(CFLAGS) -Imulticlust_amd/host -shared -o $@ $(HOST_SRC) -L$(LIB) -lmulticlust_hip -Wl,-rpath,'$$ORIGIN' -lm -lpthread
 
 # the drop-in command line (same flags, reader and output files as the reference's `multiclust`)
 $(BIN)/multiclust: multiclust_amd/host/mc_main.c $(LIB)/libmulticlust_host.so

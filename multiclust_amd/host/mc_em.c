@@ -6,9 +6,11 @@
 #include "mc_host.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 static const char *accel_abbrev[] = { "EM", "S1", "S2", "S3", "QN" };
 
@@ -230,6 +232,49 @@ static int initialize_mixture(const mc_data *dat, mc_model *mod, mc_rng *rng)
 	return rc;
 }
 
+/* assign[j] = rand() % K for j = 0..n-1 in stream order (rnd_init.c:467).  Large draws are split over host threads:
+ * thread t starts from the stream jumped ahead to its first draw (mc_rng_jump), so the result is the serial one. */
+typedef struct draw_job { uint8_t *out; size_t n; int K; mc_rng rng; } draw_job;
+
+static void *draw_main(void *arg)
+{
+	draw_job *j = arg;
+	for (size_t x = 0; x < j->n; x++) j->out[x] = (uint8_t)(mc_rand(&j->rng) % j->K);
+	return NULL;
+}
+
+static void draw_partition(uint8_t *assign, size_t n, int K, mc_rng *rng)
+{
+	int nt = 1;
+	if (n >= ((size_t)1 << 24)) {
+		long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+		nt = cpus > 16 ? 16 : (cpus < 1 ? 1 : (int)cpus);
+		if (getenv("MC_INIT_THREADS")) nt = atoi(getenv("MC_INIT_THREADS")) > 0 ? atoi(getenv("MC_INIT_THREADS")) : nt;
+	}
+	if (nt <= 1) {
+		for (size_t j = 0; j < n; j++) assign[j] = (uint8_t)(mc_rand(rng) % K);
+		return;
+	}
+	draw_job jobs[64];
+	pthread_t th[64];
+	if (nt > 64) nt = 64;
+	const size_t per = (n + (size_t)nt - 1) / (size_t)nt;
+	for (int t = 0; t < nt; t++) {
+		const size_t lo = (size_t)t * per, hi = lo + per < n ? lo + per : n;
+		jobs[t].out = assign + lo;
+		jobs[t].n = lo < n ? hi - lo : 0;
+		jobs[t].K = K;
+		jobs[t].rng = *rng;
+		mc_rng_jump(&jobs[t].rng, (uint64_t)lo);
+		if (pthread_create(&th[t], NULL, draw_main, &jobs[t])) { draw_main(&jobs[t]); th[t] = 0; }
+	}
+	for (int t = 0; t < nt; t++) if (th[t]) pthread_join(th[t], NULL);
+	mc_rng_jump(rng, (uint64_t)n);		/* the caller's stream ends where the serial loop would */
+}
+
+/* test hook for tests/test_shard_cpu.py */
+void mc_test_draw_partition(uint8_t *assign, size_t n, int K, mc_rng *rng) { draw_partition(assign, n, K, rng); }
+
 int mc_initialize_model(const mc_options *opt, const mc_data *dat, mc_model *mod, mc_rng *rng)
 {
 	/* rnd_init.c:54-89 reset, then random_initialize_admixture (349-357): one rand() % K per allele copy in
@@ -244,7 +289,7 @@ int mc_initialize_model(const mc_options *opt, const mc_data *dat, mc_model *mod
 	if (!opt->admixture)
 		return dev_fail(mod, initialize_mixture(dat, mod, rng), "mc_initialize_model");
 	if (!(assign = malloc(n))) return MCHIP_ERR_ALLOC;
-	for (size_t j = 0; j < n; j++) assign[j] = (uint8_t)(mc_rand(rng) % mod->K);
+	draw_partition(assign, n, mod->K, rng);
 	rc = mchip_mstep_from_partition(mod->dev, assign, mod->tindex);
 	free(assign);
 	return dev_fail(mod, rc, "mc_initialize_model");

@@ -120,3 +120,29 @@ def test_two_rank_gloo_sharded_initialisations_reproduce_serial_reference(name, 
     assert tail[0][3] == int(np.argmax(ref[:, 0])) and shard.owner_of(int(tail[0][3]), world) in (0, 1)
     assert tail[1][0] == g.m["mi_max_logL"] and tail[1][1] == g.m["mi_first_max_logL"]
     assert tail[1][2] == g.m["mi_n_maxll_init"] and tail[1][3] == g.m["mi_n_max_iter"]
+
+
+def test_threaded_partition_draw_equals_serial_stream():
+    """mc_initialize_model draws large partitions on several host threads, each starting from the jumped-ahead
+    stream: byte-identical to the serial rand() % K sequence, and the caller's stream ends at the same position."""
+    lib = host.load()
+    lib.mc_test_draw_partition.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(host.McRng)]
+    n, K = (1 << 24) + 12345, 7
+    os.environ["MC_INIT_THREADS"] = "5"
+    a = np.empty(n, dtype=np.uint8)
+    g = host.McRng()
+    lib.mc_srand(C.byref(g), 99)
+    lib.mc_test_draw_partition(a.ctypes.data, n, K, C.byref(g))
+    del os.environ["MC_INIT_THREADS"]
+    g2 = host.McRng()
+    lib.mc_srand(C.byref(g2), 99)
+    ref = np.array([lib.mc_rand(C.byref(g2)) % K for _ in range(200000)], dtype=np.uint8)
+    assert np.array_equal(a[:200000], ref)
+    lib.mc_rng_jump(C.byref(g2), n - 200000)
+    assert [lib.mc_rand(C.byref(g)) for _ in range(8)] == [lib.mc_rand(C.byref(g2)) for _ in range(8)]
+    # a slice in the middle of another thread's range
+    g3 = host.McRng()
+    lib.mc_srand(C.byref(g3), 99)
+    lo = 3 * ((n + 4) // 5) + 17
+    lib.mc_rng_jump(C.byref(g3), lo)
+    assert np.array_equal(a[lo:lo + 1000], np.array([lib.mc_rand(C.byref(g3)) % K for _ in range(1000)], dtype=np.uint8))
