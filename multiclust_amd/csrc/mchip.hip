@@ -486,7 +486,7 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	free_model(ctx);	/* workspaces depend on T */
 	free_data(ctx);
 
-	std::vector<int32_t> toff(L + 1);
+	std::vector<int32_t> toff(L + 9);	/* padded: kernels read 8 offsets per locus block */
 	toff[0] = 0;
 	int maxM = 0;
 	for (int l = 0; l < L; l++) {
@@ -496,6 +496,7 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 		if (ua[l] > maxM) maxM = ua[l];
 	}
 	const int T = toff[L];
+	for (int x = L + 1; x < L + 9; x++) toff[x] = T;
 	if (T <= 0) return fail(ctx, MCHIP_ERR_INVALID, "no alleles%s", nullptr);
 	std::vector<int32_t> col_locus(T);
 	std::vector<uint8_t> col_allele(T);
@@ -511,7 +512,7 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	uint8_t *d_raw = nullptr;
 	int *d_bad = nullptr;
 	HIPCHK(hipMalloc((void **)&ctx->d_ua, sizeof(int32_t) * L));
-	HIPCHK(hipMalloc((void **)&ctx->d_toff, sizeof(int32_t) * (L + 1)));
+	HIPCHK(hipMalloc((void **)&ctx->d_toff, sizeof(int32_t) * (L + 9)));
 	HIPCHK(hipMalloc((void **)&ctx->d_col_locus, sizeof(int32_t) * T));
 	HIPCHK(hipMalloc((void **)&ctx->d_col_allele, T));
 	HIPCHK(hipMalloc((void **)&ctx->d_gtA, ctx->geno_bytes_A));
@@ -519,7 +520,7 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	HIPCHK(hipMalloc((void **)&d_raw, raw_bytes));
 	HIPCHK(hipMalloc((void **)&d_bad, sizeof(int)));
 	HIPCHK(hipMemcpyAsync(ctx->d_ua, ua, sizeof(int32_t) * L, hipMemcpyHostToDevice, ctx->stream));
-	HIPCHK(hipMemcpyAsync(ctx->d_toff, toff.data(), sizeof(int32_t) * (L + 1), hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipMemcpyAsync(ctx->d_toff, toff.data(), sizeof(int32_t) * (L + 9), hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(ctx->d_col_locus, col_locus.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(ctx->d_col_allele, col_allele.data(), T, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(d_raw, geno, raw_bytes, hipMemcpyHostToDevice, ctx->stream));

@@ -414,11 +414,15 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_sparse(mchip_pass_args a)
 				dst[(x / K) * KP + (x % K)] = a.P[(size_t)n_lo * K + x];
 		}
 		gn.load(a.gtS, (size_t)min(lb + 1, lb_end - 1) * a.I + i, pl);
+		/* the block's eight locus offsets in one scalar load (toff is padded by 8 entries), instead of one s_load + wait
+		 * at the head of every locus */
+		int tb[8];
 #pragma unroll
-		for (int j = 0; j < 8; j++) {
-			const int l = lb * 8 + j;
-			if (l >= l1) break;			/* wave-uniform */
-			const int base = a.toff[l] - c_lo;
+		for (int j = 0; j < 8; j++) tb[j] = a.toff[lb * 8 + j];
+		/* one locus: all of its copies; a lambda so that full blocks run as straight-line code (no per-locus bound check:
+		 * the scheduler can then start the next locus's LDS reads under this locus's arithmetic) */
+		auto one_locus = [&](int j) __attribute__((always_inline)) {
+			const int base = tb[j] - c_lo;
 			if constexpr (PL == 2 || PL == 4) {
 				/* all copies of the locus first (t), then one shared reciprocal for each pair of copies */
 				double pc[PL ? PL : 1][KP], t[PL ? PL : 1];
@@ -490,6 +494,12 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_sparse(mchip_pass_args a)
 					}
 				}
 			}
+		};
+		if (lb * 8 + 8 <= l1) {
+#pragma unroll
+			for (int j = 0; j < 8; j++) one_locus(j);
+		} else {
+			for (int j = 0; j < 8 && lb * 8 + j < l1; j++) one_locus(j);
 		}
 		if (!SAFE) {
 			if (++blk >= a.flush_blocks) {
