@@ -181,6 +181,7 @@ def test_mixture_vs_oracle_synthetic(ctx):
 
 @pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,opts", [
     (70, 150, 3, 2, 40, 0.0, {}),                                   # > 32 alleles at a locus: dense fallback kernels
+    (300, 40, 3, 2, 120, 0.0, {}),                                  # > 64 alleles: projection with byte flags instead of a 64-bit mask
     (90, 210, 4, 1, 3, 0.02, {}),                                   # haploid
     (50, 120, 3, 3, 4, 0.03, {}),                                   # triploid: generic copy loop, 2-bit counts
     (40, 100, 2, 6, 5, 0.0, {}),                                    # hexaploid: generic copy loop, 4-bit counts
