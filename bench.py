@@ -136,16 +136,17 @@ def secondary_run(name, dev, local_rank, steps=300):
     ua, geno = gen_dataset(w["I"], w["L"], w["K"], w["ploidy"], w["maxal"], 20250117 + 2, dev)
     fit = host.Fit(ua, geno, w["K"], device=local_rank, admixture=1, accel_scheme=w["accel"], verbosity=1, abs_error=1e-300)
     fit.initialize(1234567)
-    step = fit.accelerated_em_step if w["accel"] else fit.em_step
     for _ in range(5):
-        step()
-    n0 = fit.mod.n_iter
+        fit.em_step()
+    st = hip.RunState(logL=fit.mod.logL, abs_error=1e-300, n_iter=fit.mod.n_iter)
+    lib, ctx = hip.load(), C.c_void_p(fit.mod.dev)
+    lib.mchip_synchronize(ctx)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    hip.load().mchip_synchronize(C.c_void_p(fit.mod.dev))
+    rc = lib.mchip_em_run(ctx, 0, steps, C.byref(st))       # plain EM: one batch, stopping rule on the device
     dt = time.perf_counter() - t0
-    out = {"workload": "%s: %s" % (name, w["desc"]), "value": (fit.mod.n_iter - n0) / dt, "unit": "EM iterations/s",
+    if rc or st.fatal or st.stopped:
+        raise SystemExit("secondary run failed")
+    out = {"workload": "%s: %s" % (name, w["desc"]), "value": steps / dt, "unit": "EM iterations/s",
            "ms_per_step": dt * 1e3 / steps, "steps": steps}
     fit.close()
     return out
@@ -224,12 +225,24 @@ def main():
         torch.cuda.synchronize()
         hlib.mchip_synchronize(ctx)
 
+    def run_steps(n):
+        """n steps of the hot path as the host driver runs them: SQUAREM cycles one by one (each needs its log
+        likelihoods on the host), plain EM as ONE batch whose stopping rule runs on the device (mc_em's own path)."""
+        if accel:
+            for _ in range(n):
+                one_step()
+            return
+        st = hip.RunState(logL=fit.mod.logL, abs_error=1e-300, n_iter=fit.mod.n_iter)
+        rc = hlib.mchip_em_run(ctx, 0, n, C.byref(st))
+        if rc or st.fatal or st.stopped:
+            raise SystemExit("mchip_em_run: rc=%d fatal=%d stopped=%d" % (rc, st.fatal, st.stopped))
+        fit.mod.n_iter, fit.mod.logL = st.n_iter, st.logL
+
     barrier()
     n_iter0 = fit.mod.n_iter
     hlib.mchip_profile_begin(ctx)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    run_steps(args.steps)
     best = torch.tensor([fit.mod.logL], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(best, op=dist.ReduceOp.MAX)     # the path's one exchange: best log likelihood over units

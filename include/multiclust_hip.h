@@ -87,6 +87,26 @@ int mchip_p_length(const mchip_context *ctx, int *n);	/* K*T */
  */
 int mchip_em_step(mchip_context *ctx, int from, int to, double *loglik);
 int mchip_last_loglik(mchip_context *ctx, double *loglik);
+/*
+ * A batch of in-place EM iterations with the stopping rule evaluated on the device: n_steps times
+ * { em_step(slot -> slot); stop() } exactly as em() sequences them for the unaccelerated case (em_alg.c:78-88, 101-182),
+ * enqueued without a host round trip per iteration; once the rule fires (convergence, iteration cap, NaN, decrease) the
+ * remaining steps of the batch are no-ops, so parameters, n_iter and logL are those of the stopping iteration.
+ * `state` is in/out: the host seeds it with model::logL / n_iter and reads back where the loop stands.
+ * Available for the admixture model with individual mixing proportions; otherwise MCHIP_ERR_UNSUPPORTED (the caller
+ * then iterates mchip_em_step).
+ */
+typedef struct mchip_run_state {
+	double logL;		/* model::logL: log likelihood of the previous iteration (in), of the last executed one (out) */
+	double bad_loglik;	/* the offending value when fatal != 0 */
+	double abs_error, rel_error;	/* options::abs_error / rel_error */
+	int n_iter;		/* model::n_iter */
+	int max_iter;		/* options::max_iter (0 = unlimited) */
+	int stopped, converged, iter_stop;
+	int fatal;		/* 0, 1 = NaN log likelihood, 2 = log likelihood decrease (em_alg.c:106-120) */
+} mchip_run_state;
+int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *state);
+
 /* E step only (em_e_step's trailing E step, em_alg.c:226,230): refreshes the expected counts, returns logL. */
 int mchip_e_step(mchip_context *ctx, int slot, double *loglik);
 /* log_likelihood(): logL_admixture / logL_mixture (log_likelihood.c:96-147, 157-232). */

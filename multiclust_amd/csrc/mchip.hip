@@ -57,10 +57,13 @@ struct mchip_context {
 	double *d_logp;			/* mixture model: log P table [T][K] */
 	/* workspaces */
 	int ichunk, n_ichunks, lchunk, n_lchunks, n_llpart, n_ll_col, n_ll_ind, flush_blocks, sparse;
+	double *d_ssum;			/* [I][K] chunk-summed S-side sums */
 	double *d_Apart, *d_Spart, *d_llpart, *d_scalars;	/* d_scalars: [0]=logL, [1..3]=dots, [4..]=eta sums */
 	double *d_redpart;		/* block partials of the dot products / column sums */
 	uint8_t *d_flags;		/* michelot "fixed" flags for loci with more than 64 alleles */
 	double *h_pinned;		/* 64 doubles */
+	mchip_run_state *d_run;		/* batched-run state (mchip_em_run) */
+	hipGraphExec_t step_graph[3];	/* one captured {EM step + stop check} per slot; rebuilt when the model changes */
 	int have_ll;
 	/* profiling */
 	int profiling;
@@ -171,9 +174,10 @@ __global__ void k_transpose_tk_to_kt(const double *__restrict__ src, double *__r
 }
 
 /* deterministic sum of n doubles (fixed strided order, then a fixed tree): one block */
-__global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_sum(const double *__restrict__ in, int n, double *out)
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_sum(const double *__restrict__ in, int n, double *out, const int *stop = nullptr)
 {
 	__shared__ double red[MCHIP_BLOCK];
+	if (stop && *stop) return;
 	double s = 0.0;
 	for (int x = threadIdx.x; x < n; x += MCHIP_BLOCK) s += in[x];
 	red[threadIdx.x] = s;
@@ -183,6 +187,29 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_sum(const double *__rest
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) *out = red[0];
+}
+
+/* out[e] = sum over slabs of slabs[j][e], in a fixed order: a block handles 32 elements x 8 slab lanes (lane s adds
+ * slabs s, s+8, ...; the 8 partial sums are then added in lane order), so the many per-chunk partial-sum slabs of the
+ * individual pass are combined with element- AND slab-level parallelism instead of one serial loop per individual */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_sum_slabs(const double *__restrict__ slabs, int n_slabs, size_t n, double *out,
+		const int *stop)
+{
+	__shared__ double part[8][32];
+	if (stop && *stop) return;
+	const int e_local = threadIdx.x & 31, s = threadIdx.x >> 5;
+	const size_t e = (size_t)blockIdx.x * 32 + e_local;
+	double acc = 0.0;
+	if (e < n)
+		for (int j = s; j < n_slabs; j += 8) acc += slabs[(size_t)j * n + e];
+	part[s][e_local] = acc;
+	__syncthreads();
+	if (s == 0 && e < n) {
+		double t = part[0][e_local];
+#pragma unroll
+		for (int x = 1; x < 8; x++) t += part[x][e_local];
+		out[e] = t;
+	}
 }
 
 /* simplex.c:109-143 on a strided vector in memory; fixed-entry set kept in a 64-bit mask (len <= 64)
@@ -216,10 +243,10 @@ __device__ void michelot_strided(double *x, int stride, int len, double mn, uint
 /* P[to][l,.][k] = normalise(P[from] * sum_chunks Apart) then project (em_alg.c:706-752); thread = (l,k) */
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_p(int L, int K, int T, const int32_t *__restrict__ toff,
 		int n_ichunks, const double *__restrict__ Apart, const double *Pfrom, double *Pto,
-		int weighted, double add_lb, int do_projection, double lb, uint8_t *flags)
+		int weighted, double add_lb, int do_projection, double lb, uint8_t *flags, const int *stop = nullptr)
 {
 	const size_t idx = (size_t)blockIdx.x * MCHIP_BLOCK + threadIdx.x;
-	if (idx >= (size_t)L * K) return;
+	if (idx >= (size_t)L * K || (stop && *stop)) return;
 	const int k = (int)(idx % K);
 	const int l = (int)(idx / K);
 	const int c0 = toff[l], M = toff[l + 1] - c0;
@@ -280,6 +307,41 @@ __global__ void k_logp(const double *__restrict__ p, double *__restrict__ out, s
 	if (idx >= n) return;
 	const double v = p[idx];
 	out[idx] = (skip_zero && v == 0.0) ? 0.0 : log(v);
+}
+
+/* stop() + stop_condition() + converged() of em_alg.c:101-182 on the device (time limit excepted), one thread */
+__global__ void k_stop_check(mchip_run_state *s, const double *ll)
+{
+	if (threadIdx.x || blockIdx.x || s->stopped) return;
+	const double loglik = *ll;
+	s->n_iter++;
+	if (loglik != loglik) {
+		s->fatal = 1;
+		s->bad_loglik = loglik;
+		s->stopped = 1;
+		return;
+	}
+	int stop;
+	if (s->max_iter && s->n_iter > s->max_iter) {
+		s->iter_stop = 1;
+		stop = 1;
+	} else {
+		double abs_diff = 0, rel_diff = 0;
+		stop = 1;
+		if (s->abs_error != 0) abs_diff = fabs(loglik - s->logL);
+		if (s->rel_error != 0) rel_diff = abs_diff / fabs(s->logL);
+		if (s->abs_error != 0 && abs_diff > s->abs_error) stop = 0;
+		if (s->rel_error != 0 && rel_diff > s->rel_error) stop = 0;
+		if (stop) s->converged = 1;
+	}
+	s->stopped = stop;
+	if (loglik < s->logL && !stop) {
+		s->fatal = 2;
+		s->bad_loglik = loglik;
+		s->stopped = 1;
+		return;
+	}
+	s->logL = loglik;
 }
 
 /* secant: out = x_to - x_from (em_alg.c:1104-1161) */
@@ -367,9 +429,11 @@ static void prof_mark(mchip_context *ctx, int kind, bool start)
 
 static void free_model(mchip_context *ctx)
 {
+	for (int s = 0; s < 3; s++)
+		if (ctx->step_graph[s]) { (void)hipGraphExecDestroy(ctx->step_graph[s]); ctx->step_graph[s] = nullptr; }
 	for (int s = 0; s < 3; s++) { dfree(ctx->d_p[s]); dfree(ctx->d_q[s]); }
 	for (int s = 0; s < MCHIP_MAX_SECANTS; s++) { dfree(ctx->d_up[s]); dfree(ctx->d_vp[s]); dfree(ctx->d_uq[s]); dfree(ctx->d_vq[s]); }
-	dfree(ctx->d_sik); dfree(ctx->d_stage); dfree(ctx->d_logp); dfree(ctx->d_Apart); dfree(ctx->d_Spart); dfree(ctx->d_llpart);
+	dfree(ctx->d_sik); dfree(ctx->d_stage); dfree(ctx->d_logp); dfree(ctx->d_ssum); dfree(ctx->d_Apart); dfree(ctx->d_Spart); dfree(ctx->d_llpart);
 	dfree(ctx->d_redpart); dfree(ctx->d_flags);
 	ctx->K = 0;
 	ctx->kt = nullptr;
@@ -431,6 +495,7 @@ int mchip_create(mchip_context **out, int device)
 	ctx->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
 	if (hipHostMalloc((void **)&ctx->h_pinned, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
 	    hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(double)) != hipSuccess ||
+	    hipMalloc((void **)&ctx->d_run, sizeof(mchip_run_state)) != hipSuccess ||
 	    hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
 		delete ctx;
 		return MCHIP_ERR_ALLOC;
@@ -447,6 +512,7 @@ int mchip_destroy(mchip_context *ctx)
 	free_model(ctx);
 	free_data(ctx);
 	dfree(ctx->d_scalars);
+	dfree(ctx->d_run);
 	if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
 	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
 	(void)hipEventDestroy(ctx->ev_begin);
@@ -591,6 +657,7 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	HIPCHK(hipMalloc((void **)&ctx->d_sik, (size_t)ctx->I * K * sizeof(double)));
 	HIPCHK(hipMemsetAsync(ctx->d_sik, 0, (size_t)ctx->I * K * sizeof(double), ctx->stream));
 	HIPCHK(hipMalloc((void **)&ctx->d_stage, KT * sizeof(double)));
+	HIPCHK(hipMalloc((void **)&ctx->d_ssum, (size_t)ctx->I * K * sizeof(double)));
 	if (!admixture) HIPCHK(hipMalloc((void **)&ctx->d_logp, KT * sizeof(double)));
 
 	/* launch geometry.  Both passes are FP64-issue-bound and every workgroup does the same amount of work, so
@@ -771,10 +838,11 @@ static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int m
 	return MCHIP_OK;
 }
 
-static int run_estep(mchip_context *ctx, int from, int to, int do_mstep)
+static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const int *stop = nullptr)
 {
 	if (!ctx->admixture) return run_mixture(ctx, from, to, do_mstep, 0);
 	mchip_pass_args a = pass_args(ctx, from);
+	a.stop = stop;
 	if (do_mstep || !ctx->sparse) {
 		prof_mark(ctx, MCHIP_KERN_ACCUM_P, true);
 		if (do_mstep) ctx->kt->accum_p(a, ctx->stream); else ctx->kt->loglik(a, ctx->stream);
@@ -784,10 +852,14 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep)
 	ctx->kt->accum_q(a, ctx->stream);
 	prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
 	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart,
-			   ctx->sparse ? ctx->n_ll_ind : ctx->n_ll_col, ctx->d_scalars);
+			   ctx->sparse ? ctx->n_ll_ind : ctx->n_ll_col, ctx->d_scalars, stop);
 	const int indiv = ctx->qstride != 0;
-	ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[from], ctx->qstride,
-			    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, ctx->stream);
+	{
+		const size_t n = (size_t)ctx->I * ctx->K;
+		hipLaunchKernelGGL(k_sum_slabs, dim3(nblk(n, 32)), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_Spart, ctx->n_lchunks, n, ctx->d_ssum, stop);
+	}
+	ctx->kt->finalize_q(ctx->I, ctx->K, 1, ctx->d_ssum, ctx->d_q[from], ctx->qstride,
+			    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream);
 	if (do_mstep) {
 		if (!indiv) {
 			int rc = finalize_shared_eta(ctx, to);
@@ -795,10 +867,50 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep)
 		}
 		hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
 				   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
-				   1, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags);
+				   1, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags, stop);
 	}
 	HIPCHK(hipGetLastError());
 	ctx->have_ll = 1;
+	return MCHIP_OK;
+}
+
+int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *state)
+{
+	int rc = check_slot(ctx, slot);
+	if (rc) return rc;
+	if (!state || n_steps < 1) return fail(ctx, MCHIP_ERR_INVALID, "em_run: bad arguments%s", nullptr);
+	if (!ctx->admixture || !ctx->qstride) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "em_run: admixture model with individual mixing proportions only%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipMemcpyAsync(ctx->d_run, state, sizeof *state, hipMemcpyHostToDevice, ctx->stream));
+	const int *stop = &ctx->d_run->stopped;
+	/* The step is a launch-bound chain of 6-7 kernels on small data sets: capture it once into a hipGraph and replay it
+	 * (eager launches cost ~8 us of host time each here, graph nodes ~1.5 us of device time).  Event marks cannot be
+	 * captured, so profiled runs stay eager. */
+	bool use_graph = !ctx->profiling && n_steps >= 4 && !getenv("MCHIP_NO_GRAPH");
+	if (use_graph && !ctx->step_graph[slot]) {
+		hipGraph_t graph = nullptr;
+		if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+			rc = run_estep(ctx, slot, slot, 1, stop);
+			hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(64), 0, ctx->stream, ctx->d_run, ctx->d_scalars);
+			const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+			if (rc || e != hipSuccess || !graph || hipGraphInstantiate(&ctx->step_graph[slot], graph, nullptr, nullptr, 0) != hipSuccess)
+				ctx->step_graph[slot] = nullptr;
+			if (graph) (void)hipGraphDestroy(graph);
+			(void)hipGetLastError();
+		}
+		if (!ctx->step_graph[slot]) use_graph = false;	/* capture unavailable: eager path below */
+	}
+	for (int s = 0; s < n_steps; s++) {
+		if (use_graph) {
+			HIPCHK(hipGraphLaunch(ctx->step_graph[slot], ctx->stream));
+			continue;
+		}
+		if ((rc = run_estep(ctx, slot, slot, 1, stop))) return rc;
+		hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(64), 0, ctx->stream, ctx->d_run, ctx->d_scalars);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(state, ctx->d_run, sizeof *state, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
 	return MCHIP_OK;
 }
 
@@ -884,7 +996,7 @@ int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to
 	ctx->kt->part_q(a, ctx->stream);
 	const int indiv = ctx->qstride != 0;
 	ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[to], ctx->qstride,
-			    ctx->d_q[to], ctx->d_sik, indiv, 0, ctx->do_projection, ctx->eta_lb, ctx->stream);
+			    ctx->d_q[to], ctx->d_sik, indiv, 0, ctx->do_projection, ctx->eta_lb, nullptr, ctx->stream);
 	if (!indiv && (rc = finalize_shared_eta(ctx, to))) return rc;
 	hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
 			   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[to], ctx->d_p[to],

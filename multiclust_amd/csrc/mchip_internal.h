@@ -49,6 +49,8 @@ struct mchip_pass_args {
 	/* sparse individual pass: P rows of 8 loci staged in LDS */
 	int sparse;		/* 1: sparse individual pass + N-only column pass; 0: dense pair */
 	int tile_cols;		/* LDS tile capacity in allele columns (8 * max alleles per locus) */
+	/* batched runs: when non-null and *stop != 0 every kernel of the step returns at once */
+	const int *stop;
 	/* hard-partition first M step */
 	const uint8_t *asA, *asS;	/* assignment bytes in the gtA / gtS layouts */
 };
@@ -62,7 +64,7 @@ struct mchip_ktable {
 	void (*part_q)(const mchip_pass_args &a, hipStream_t s);	/* hard partition, individual pass */
 	/* finalize: Q[to] from Spart (normalise + project), stores expected counts */
 	void (*finalize_q)(int I, int K, int n_lchunks, const double *Spart, const double *Qfrom, int qstride_from,
-			   double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, hipStream_t s);
+			   double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, const int *stop, hipStream_t s);
 	void (*project_q)(int nrows, int K, double *Q, double lb, hipStream_t s);
 	/* mixture model */
 	void (*mix_gather)(const mchip_pass_args &a, hipStream_t s);	/* a.P = log P table; Spart = per-chunk sums */

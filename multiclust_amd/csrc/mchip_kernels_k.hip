@@ -149,6 +149,7 @@ template <int NT> __device__ __forceinline__ double block_sum(double v, double *
 template <int PL, bool ACCUM, bool SAFE, bool LL>
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_pass(mchip_pass_args a)
 {
+	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
 	__shared__ double red[MCHIP_BLOCK];
 	const int c_raw = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
 	const bool valid = c_raw < a.T;
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_pass(mchip_pass_args a)
 template <int BITS, bool MIX>
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a)
 {
+	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
 	constexpr int PERWORD = 32 / BITS;		/* individuals per dword */
 	constexpr int G = 4 * PERWORD;			/* individuals per 16-byte word */
 	constexpr unsigned MASK = (1u << BITS) - 1u;
@@ -307,6 +309,7 @@ constexpr int QBLOCK = 128;
 template <int PL>
 __global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
 {
+	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
 	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
 	const bool active = i_raw < a.I;
 	const int i = active ? i_raw : a.I - 1;
@@ -373,6 +376,7 @@ constexpr int KP = (K + 1) & ~1;	/* LDS row stride in doubles: rows stay 16-byte
 template <int PL, bool ACCUM, bool SAFE, bool NOMISS>
 __global__ __launch_bounds__(QBLOCK) void k_individual_sparse(mchip_pass_args a)
 {
+	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
 	extern __shared__ __attribute__((aligned(16))) double lds[];	/* [2][tile_cols][KP] then [QBLOCK] reduction scratch */
 	double *red = lds + 2 * (size_t)a.tile_cols * KP;
 	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
@@ -779,10 +783,10 @@ __device__ __forceinline__ void michelot_k(double (&x)[K], double mn)
  * expected counts S_ik the writers need (write_file.c:359-381). */
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_q(int I, int n_lchunks, const double *__restrict__ Spart,
 		const double *__restrict__ Qfrom, int qstride_from, double *Qto, double *sik,
-		int do_mstep, int weighted, int do_projection, double lb)
+		int do_mstep, int weighted, int do_projection, double lb, const int *stop)
 {
 	const int i = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
-	if (i >= I) return;
+	if (i >= I || (stop && *stop)) return;
 	double s[K];
 #pragma unroll
 	for (int k = 0; k < K; k++) s[k] = 0.0;
@@ -904,10 +908,10 @@ void launch_part_q(const mchip_pass_args &a, hipStream_t s)
 	else hipLaunchKernelGGL((k_partition_individuals<0>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
 }
 void launch_finalize_q(int I, int, int n_lchunks, const double *Spart, const double *Qfrom, int qstride_from,
-		       double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, hipStream_t s)
+		       double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, const int *stop, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_finalize_q, dim3((I + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s,
-			   I, n_lchunks, Spart, Qfrom, qstride_from, Qto, sik, do_mstep, weighted, do_projection, lb);
+			   I, n_lchunks, Spart, Qfrom, qstride_from, Qto, sik, do_mstep, weighted, do_projection, lb, stop);
 }
 void launch_project_q(int nrows, int, double *Q, double lb, hipStream_t s)
 {

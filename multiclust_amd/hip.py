@@ -13,6 +13,13 @@ class HipError(RuntimeError):
     pass
 
 
+class RunState(C.Structure):
+    """mchip_run_state (include/multiclust_hip.h)"""
+    _fields_ = [("logL", C.c_double), ("bad_loglik", C.c_double), ("abs_error", C.c_double), ("rel_error", C.c_double),
+                ("n_iter", C.c_int), ("max_iter", C.c_int), ("stopped", C.c_int), ("converged", C.c_int),
+                ("iter_stop", C.c_int), ("fatal", C.c_int)]
+
+
 def lib_path():
     return os.path.join(_HERE, "lib", "libmulticlust_hip.so")
 
@@ -48,6 +55,7 @@ def load():
         "mchip_p_length": ([vp, ip], i32),
         "mchip_em_step": ([vp, i32, i32, dp], i32),
         "mchip_last_loglik": ([vp, dp], i32),
+        "mchip_em_run": ([vp, i32, i32, vp], i32),
         "mchip_e_step": ([vp, i32, dp], i32),
         "mchip_loglik": ([vp, i32, dp], i32),
         "mchip_mstep_from_partition": ([vp, vp, i32], i32),
@@ -76,7 +84,7 @@ def load():
 ABI_SYMBOLS = [
     "mchip_abi_version", "mchip_device_count", "mchip_create", "mchip_destroy", "mchip_last_error",
     "mchip_synchronize", "mchip_set_genotypes", "mchip_set_model", "mchip_set_p", "mchip_get_p", "mchip_set_q",
-    "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_last_loglik", "mchip_e_step",
+    "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_em_run", "mchip_last_loglik", "mchip_e_step",
     "mchip_loglik", "mchip_mstep_from_partition", "mchip_get_expected_counts", "mchip_secant", "mchip_step_dots",
     "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
     "mchip_profile_end", "mchip_device_info", "mchip_comm_create", "mchip_comm_all_reduce", "mchip_comm_destroy",

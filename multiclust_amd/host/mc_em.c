@@ -543,6 +543,42 @@ EM_EXIT:
 	return 0;
 }
 
+/* Unaccelerated loop of em() (em_alg.c:61-64,78-88) in batches whose stopping rule runs on the device
+ * (mchip_em_run): same arithmetic, same stopping iteration, no host round trip per iteration.  Used when nothing has to
+ * be printed per iteration and no wall-clock limit applies; returns -1 when the device path does not cover the model. */
+#define MC_EM_BATCH 32
+static int em_batched(const mc_options *opt, mc_model *mod)
+{
+	while (!mod->stopped) {
+		mchip_run_state st;
+		memset(&st, 0, sizeof st);
+		st.logL = mod->logL;
+		st.abs_error = opt->abs_error;
+		st.rel_error = opt->rel_error;
+		st.n_iter = mod->n_iter;
+		st.max_iter = opt->max_iter;
+		const int rc = mchip_em_run(mod->dev, mod->findex, MC_EM_BATCH, &st);
+		if (rc == MCHIP_ERR_UNSUPPORTED) return -1;
+		if (dev_fail(mod, rc, "mc_em")) return 0;
+		mod->n_iter = st.n_iter;
+		mod->logL = st.logL;
+		mod->accel_step = 0;
+		if (st.converged) mod->converged = 1;
+		if (st.iter_stop) mod->iter_stop = 1;
+		mod->stopped = st.stopped;
+		mod->seconds_run = ((double)clock() - mod->start) / CLOCKS_PER_SEC;
+		if (st.fatal == 1) {
+			fprintf(stderr, "ERROR [em_alg.c::stop(107)]: nan\n");
+			mod->fatal = MC_FATAL_NAN;
+		} else if (st.fatal == 2) {
+			fprintf(stderr, "ERROR [em_alg.c::stop(116)]: log likelihood decrease (%f < %f; %e)\n",
+				st.bad_loglik, st.logL, (st.bad_loglik - st.logL) / st.bad_loglik);
+			mod->fatal = MC_FATAL_DECREASE;
+		}
+	}
+	return 0;
+}
+
 void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod)
 {
 	/* em_alg.c:44-90 */
@@ -552,6 +588,9 @@ void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod)
 		if (!mod->fatal) mod->logL = mc_log_likelihood(opt, dat, mod, mod->tindex);
 		return;
 	}
+	if (!opt->accel_scheme && opt->admixture && !opt->eta_constrained && opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
+	    !getenv("MC_NO_BATCH") && em_batched(opt, mod) == 0)
+		return;
 	while (mod->n_iter < opt->n_init_iter && !stop)
 		stop = mc_em_step(opt, dat, mod);
 	for (int i = 1; i < opt->q; i++) {

@@ -165,3 +165,35 @@ def test_fit_units_with_jump_ahead_vs_serial_reference(name):
     assert abs(s.max_logL - g.m["mi_max_logL"]) <= 0.25
     assert fit.no_parameters() == g.m["no_parameters"]
     fit.close()
+
+
+@pytest.mark.parametrize("name", ["multi_admix_k4", "missing_admix_k3", "tetra_admix_k3"])
+def test_batched_em_equals_step_by_step(name, monkeypatch):
+    """mc_em's batched loop (stopping rule on the device, mchip_em_run) against the step-by-step loop: same stopping
+    iteration, bitwise the same log likelihood and parameters."""
+    g = Golden(name)
+    res = []
+    for nobatch in (False, True):
+        if nobatch:
+            monkeypatch.setenv("MC_NO_BATCH", "1")
+        fit = make_fit(g)
+        fit.em()
+        m = fit.mod
+        res.append((m.n_iter, m.converged, m.logL, fit.get_q(m.pindex), fit.get_p(m.pindex), fit.expected_counts()))
+        fit.close()
+    a, b = res
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
+
+def test_batched_em_iteration_cap_and_decrease_detection():
+    g = Golden("multi_admix_k4")
+    fit = make_fit(g, max_iter=40)                     # cap inside the second batch of 32
+    fit.em()
+    assert fit.mod.n_iter == 41 and fit.mod.iter_stop == 1 and fit.mod.converged == 0
+    fit.close()
+    fit = make_fit(g)
+    fit.mod.logL = 0.0                                 # a "previous" log likelihood above anything reachable
+    fit.lib.mc_em(*fit._a())
+    assert fit.mod.fatal == 2 and fit.mod.n_iter == 1  # the reference would exit(0) here (em_alg.c:115-120)
+    fit.close()
