@@ -111,6 +111,11 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
 int mchip_e_step(mchip_context *ctx, int slot, double *loglik);
 /* log_likelihood(): logL_admixture / logL_mixture (log_likelihood.c:96-147, 157-232). */
 int mchip_loglik(mchip_context *ctx, int slot, double *loglik);
+/* The same value, computed by the pass that also accumulates the E step's per-individual sums and keeps them: an
+ * mchip_em_step from this slot that follows (no parameter write in between) skips that pass.  accelerated_update's
+ * log_likelihood(tindex) (accel_em.c:544) is followed, whenever the extrapolated point is accepted, by exactly such
+ * an E step at the head of the next cycle (em_alg.c:1089-1098). */
+int mchip_loglik_prefetch(mchip_context *ctx, int slot, double *loglik);
 
 /*
  * First M step from a hard allele partition: random_initialize_admixture (rnd_init.c:349-357) =

@@ -65,6 +65,7 @@ struct mchip_context {
 	mchip_run_state *d_run;		/* batched-run state (mchip_em_run) */
 	hipGraphExec_t step_graph[3];	/* one captured {EM step + stop check} per slot; rebuilt when the model changes */
 	int have_ll;
+	int s_cache_slot;		/* slot whose S-side sums + logL are held in Spart / d_scalars[2] (mchip_loglik_prefetch), or -1 */
 	/* profiling */
 	int profiling;
 	hipEvent_t ev_begin, ev_end;
@@ -438,6 +439,7 @@ static void free_model(mchip_context *ctx)
 	ctx->K = 0;
 	ctx->kt = nullptr;
 	ctx->have_ll = 0;
+	ctx->s_cache_slot = -1;
 }
 
 static void free_data(mchip_context *ctx)
@@ -743,6 +745,7 @@ int mchip_set_p(mchip_context *ctx, int slot, const double *p)
 {
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
+	ctx->s_cache_slot = -1;
 	if (!p) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
 	const size_t KT = (size_t)ctx->K * ctx->T;
 	HIPCHK(hipSetDevice(ctx->device));
@@ -771,6 +774,7 @@ int mchip_set_q(mchip_context *ctx, int slot, const double *q)
 {
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
+	ctx->s_cache_slot = -1;
 	if (!q) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(ctx->d_q[slot], q, (size_t)ctx->nq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -848,11 +852,18 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 		if (do_mstep) ctx->kt->accum_p(a, ctx->stream); else ctx->kt->loglik(a, ctx->stream);
 		prof_mark(ctx, MCHIP_KERN_ACCUM_P, false);
 	}
-	prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
-	ctx->kt->accum_q(a, ctx->stream);
-	prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
-	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart,
-			   ctx->sparse ? ctx->n_ll_ind : ctx->n_ll_col, ctx->d_scalars, stop);
+	if (ctx->sparse && do_mstep && !stop && ctx->s_cache_slot == from) {
+		/* the individual pass over these very parameters already ran (mchip_loglik_prefetch): its sums are in Spart,
+		 * its log likelihood in d_scalars[2] */
+		HIPCHK(hipMemcpyAsync(ctx->d_scalars, ctx->d_scalars + 2, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+	} else {
+		prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
+		ctx->kt->accum_q(a, ctx->stream);
+		prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
+		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart,
+				   ctx->sparse ? ctx->n_ll_ind : ctx->n_ll_col, ctx->d_scalars, stop);
+	}
+	ctx->s_cache_slot = -1;		/* Spart is consumed below; slot `to` is about to change */
 	const int indiv = ctx->qstride != 0;
 	{
 		const size_t n = (size_t)ctx->I * ctx->K;
@@ -964,10 +975,28 @@ int mchip_loglik(mchip_context *ctx, int slot, double *loglik)
 	return MCHIP_OK;
 }
 
+int mchip_loglik_prefetch(mchip_context *ctx, int slot, double *loglik)
+{
+	int rc = check_slot(ctx, slot);
+	if (rc) return rc;
+	if (!ctx->admixture || !ctx->sparse) return mchip_loglik(ctx, slot, loglik);	/* nothing to share on those paths */
+	HIPCHK(hipSetDevice(ctx->device));
+	mchip_pass_args a = pass_args(ctx, slot);
+	prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
+	ctx->kt->accum_q(a, ctx->stream);		/* S-side sums -> Spart, logL partials -> llpart */
+	prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
+	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_ll_ind, ctx->d_scalars + 2);
+	HIPCHK(hipGetLastError());
+	ctx->s_cache_slot = slot;
+	if (loglik) return fetch_scalars(ctx, 2, 1, loglik);
+	return MCHIP_OK;
+}
+
 int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to)
 {
 	int rc = check_slot(ctx, to);
 	if (rc) return rc;
+	ctx->s_cache_slot = -1;
 	if (!assign) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
 	if (!ctx->admixture) return fail(ctx, MCHIP_ERR_STATE, "allele partitions initialise the admixture model only%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
@@ -1094,6 +1123,7 @@ int mchip_accel_update(mchip_context *ctx, int to, int base, int j, double s, in
 {
 	int rc = check_secant(ctx, j);
 	if (rc) return rc;
+	ctx->s_cache_slot = -1;
 	if ((rc = check_slot(ctx, to)) || (rc = check_slot(ctx, base))) return rc;
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t KT = (size_t)ctx->K * ctx->T;
@@ -1108,6 +1138,7 @@ int mchip_multisecant_update(mchip_context *ctx, int to, int base, int u_index, 
 {
 	int rc = check_secant(ctx, u_index);
 	if (rc) return rc;
+	ctx->s_cache_slot = -1;
 	if ((rc = check_slot(ctx, to)) || (rc = check_slot(ctx, base))) return rc;
 	if (n_terms < 0 || (n_terms && (!v_index || !coef_a || !coef_b))) return MCHIP_ERR_INVALID;
 	for (int t = 0; t < n_terms; t++) if ((rc = check_secant(ctx, v_index[t]))) return rc;

@@ -58,6 +58,7 @@ def load():
         "mchip_em_run": ([vp, i32, i32, vp], i32),
         "mchip_e_step": ([vp, i32, dp], i32),
         "mchip_loglik": ([vp, i32, dp], i32),
+        "mchip_loglik_prefetch": ([vp, i32, dp], i32),
         "mchip_mstep_from_partition": ([vp, vp, i32], i32),
         "mchip_get_expected_counts": ([vp, vp], i32),
         "mchip_secant": ([vp, i32, i32, i32, i32], i32),
@@ -85,7 +86,7 @@ ABI_SYMBOLS = [
     "mchip_abi_version", "mchip_device_count", "mchip_create", "mchip_destroy", "mchip_last_error",
     "mchip_synchronize", "mchip_set_genotypes", "mchip_set_model", "mchip_set_p", "mchip_get_p", "mchip_set_q",
     "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_em_run", "mchip_last_loglik", "mchip_e_step",
-    "mchip_loglik", "mchip_mstep_from_partition", "mchip_get_expected_counts", "mchip_secant", "mchip_step_dots",
+    "mchip_loglik", "mchip_loglik_prefetch", "mchip_mstep_from_partition", "mchip_get_expected_counts", "mchip_secant", "mchip_step_dots",
     "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
     "mchip_profile_end", "mchip_device_info", "mchip_comm_create", "mchip_comm_all_reduce", "mchip_comm_destroy",
     "mchip_comm_last_error",

@@ -419,10 +419,14 @@ double mc_accelerated_update(const mc_options *opt, const mc_data *dat, mc_model
 {
 	/* accel_em.c:422-551 */
 	double ll;
+	(void)dat;
 	mod->delta_index = mod->delta_index ? mod->delta_index - 1 : opt->q - 1;
 	if (dev_fail(mod, mchip_accel_update(mod->dev, mod->tindex, mod->pindex, mod->delta_index, s,
 					     opt->accel_scheme == MC_QN), "mc_accelerated_update")) return NAN;
-	ll = mc_log_likelihood(opt, dat, mod, mod->tindex);
+	/* log_likelihood(tindex), accel_em.c:544; if this point is accepted the next cycle's first E step reads the same
+	 * slot, so the device keeps the per-individual sums of this pass for it */
+	ll = NAN;
+	if (dev_fail(mod, mchip_loglik_prefetch(mod->dev, mod->tindex, &ll), "mc_accelerated_update")) return NAN;
 	mod->delta_index = (mod->delta_index + 1) % opt->q;
 	return ll;
 }
