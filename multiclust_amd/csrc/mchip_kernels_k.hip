@@ -373,8 +373,11 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
  * stand-alone log-likelihood pass (logL_admixture, log_likelihood.c:96-147). */
 constexpr int KP = (K + 1) & ~1;	/* LDS row stride in doubles: rows stay 16-byte aligned */
 
+#ifndef MCHIP_SPARSE_WAVES
+#define MCHIP_SPARSE_WAVES 1
+#endif
 template <int PL, bool ACCUM, bool SAFE, bool NOMISS>
-__global__ __launch_bounds__(QBLOCK) void k_individual_sparse(mchip_pass_args a)
+__global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_sparse(mchip_pass_args a)
 {
 	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
 	extern __shared__ __attribute__((aligned(16))) double lds[];	/* [2][tile_cols][KP] then [QBLOCK] reduction scratch */
