@@ -1,0 +1,57 @@
+/* CPU-only sanitizer driver for the host C code (reader, writers, rand() jump-ahead, threaded partition draw, bookkeeping).
+ * Built with -fsanitize=address,undefined by tests/test_host_asan.py; the device entry points are stubbed because nothing
+ * here reaches them.  (GPU AddressSanitizer is not available on the pool: sanitizers run on the CPU build only.) */
+#include "mc_cli.h"
+#include <string.h>
+#include <stdlib.h>
+/* stubs for the device calls the linked objects reference (never reached here) */
+int mchip_create(mchip_context **c, int d){(void)c;(void)d;return 2;}
+int mchip_destroy(mchip_context *c){(void)c;return 0;}
+const char *mchip_last_error(const mchip_context *c){(void)c;return "";}
+int mchip_set_genotypes(mchip_context *c,int a,int b,int d,const int32_t*u,const uint8_t*g){(void)c;(void)a;(void)b;(void)d;(void)u;(void)g;return 2;}
+int mchip_set_model(mchip_context *c,int a,int b,int d,int e,double f,double g,int h){(void)c;(void)a;(void)b;(void)d;(void)e;(void)f;(void)g;(void)h;return 2;}
+int mchip_set_p(mchip_context*c,int s,const double*p){(void)c;(void)s;(void)p;return 2;}
+int mchip_get_p(mchip_context*c,int s,double*p){(void)c;(void)s;(void)p;return 2;}
+int mchip_set_q(mchip_context*c,int s,const double*p){(void)c;(void)s;(void)p;return 2;}
+int mchip_get_q(mchip_context*c,int s,double*p){(void)c;(void)s;(void)p;return 2;}
+int mchip_get_expected_counts(mchip_context*c,double*p){(void)c;(void)p;return 2;}
+int mchip_mstep_from_partition(mchip_context*c,const uint8_t*a,int t){(void)c;(void)a;(void)t;return 2;}
+int mchip_em_step(mchip_context*c,int a,int b,double*l){(void)c;(void)a;(void)b;(void)l;return 2;}
+int mchip_em_run(mchip_context*c,int a,int b,mchip_run_state*l){(void)c;(void)a;(void)b;(void)l;return 2;}
+int mchip_e_step(mchip_context*c,int a,double*l){(void)c;(void)a;(void)l;return 2;}
+int mchip_loglik(mchip_context*c,int a,double*l){(void)c;(void)a;(void)l;return 2;}
+int mchip_loglik_prefetch(mchip_context*c,int a,double*l){(void)c;(void)a;(void)l;return 2;}
+int mchip_secant(mchip_context*c,int a,int b,int d,int e){(void)c;(void)a;(void)b;(void)d;(void)e;return 2;}
+int mchip_step_dots(mchip_context*c,int a,double*l){(void)c;(void)a;(void)l;return 2;}
+int mchip_secant_dots(mchip_context*c,int a,int b,double*l){(void)c;(void)a;(void)b;(void)l;return 2;}
+int mchip_accel_update(mchip_context*c,int a,int b,int d,double s,int q){(void)c;(void)a;(void)b;(void)d;(void)s;(void)q;return 2;}
+int mchip_multisecant_update(mchip_context*c,int a,int b,int d,int n,const int*v,const double*x,const double*y){(void)c;(void)a;(void)b;(void)d;(void)n;(void)v;(void)x;(void)y;return 2;}
+void mc_test_draw_partition(uint8_t *assign, size_t n, int K, mc_rng *rng);
+int main(int argc, char **argv)
+{
+	for (int a = 1; a + 1 < argc; a += 2) {
+		mc_cli_options o; memset(&o, 0, sizeof o);
+		o.filename = argv[a]; o.ploidy = atoi(argv[a + 1]); o.missing_value = -9;
+		mc_cli_data d;
+		int rc = mc_read_structure(&o, &d);
+		printf("%s: rc=%d I=%d L=%d T=%d\n", argv[a], rc, d.I, d.L, d.T);
+		if (!rc) {
+			/* writers + partition on fake fit */
+			int K = 3; double *q = calloc((size_t)d.I*K,8), *p = calloc((size_t)K*d.T,8), *s = calloc((size_t)d.I*K,8); int cnt[3];
+			for (int i = 0; i < d.I*K; i++) { q[i] = 1.0/K; s[i] = i % 7; }
+			mc_fit_view fv = {K, 1, -1.0, 2.0, 3.0, q, p, s};
+			o.path = "/tmp/asan"; o.filename_file = "x.stru"; o.em.admixture = 1;
+			mc_partition(&d, &fv, NULL, cnt);
+			mc_write_results(&o, &d, &fv, cnt);
+			free(q); free(p); free(s);
+			mc_free_data(&d);
+		}
+	}
+	mc_rng g; mc_srand(&g, 5); mc_rng_jump(&g, 123456789ull);
+	uint8_t *as = malloc((1u<<24)+5); setenv("MC_INIT_THREADS","3",1);
+	mc_test_draw_partition(as, (1u<<24)+5, 5, &g); free(as);
+	mc_summary s; mc_summary_reset(&s); mc_options eo; mc_make_options(&eo);
+	mc_unit_result r = {0, -10.0, 1, 5, 0, 0, 0, 0, 0.0}; mc_summary_add(&eo, &s, &r, 10, 20);
+	printf("ok %d\n", s.n_init);
+	return 0;
+}
