@@ -179,6 +179,11 @@ class Context:
         self._chk(self.lib.mchip_loglik(self.h, slot, C.byref(ll)))
         return ll.value
 
+    def loglik_prefetch(self, slot=0):
+        ll = C.c_double()
+        self._chk(self.lib.mchip_loglik_prefetch(self.h, slot, C.byref(ll)))
+        return ll.value
+
     def mstep_from_partition(self, assign, to=0):
         a = np.ascontiguousarray(assign, dtype=np.uint8)
         assert a.size == self.I * self.L * self.ploidy

@@ -1,0 +1,102 @@
+"""-m gpu: parity at BASELINE.json's full sizes through size-independent properties (and the oracle where it finishes
+in seconds): config 2 (2 000 x 20 000, K = 5) against the oracle on the whole problem, config 3 (10 000 x 100 000,
+M_l <= 4, K = 8) against exact identities of the E/M steps and against the oracle on a slice of individuals."""
+import numpy as np
+import pytest
+
+import multiclust_amd as mc
+import oracle_bind as ob
+from synth import make_dataset, random_params
+
+pytestmark = pytest.mark.gpu
+
+
+def fast_geno(I, L, ploidy, maxal, seed, chunk=500):
+    rng = np.random.default_rng(seed)
+    ua = rng.integers(2, maxal + 1, size=L).astype(np.int32) if maxal > 2 else np.full(L, 2, np.int32)
+    geno = np.empty((I, L, ploidy), dtype=np.uint8)
+    for i0 in range(0, I, chunk):
+        i1 = min(I, i0 + chunk)
+        geno[i0:i1] = (rng.integers(0, 1 << 20, size=(i1 - i0, L, ploidy), dtype=np.int32) % ua[None, :, None]).astype(np.uint8)
+    return ua, geno
+
+
+def check_simplex(q, p, ua, lb):
+    assert np.all(q >= lb * (1 - 1e-12)) and np.all(p >= lb * (1 - 1e-12))
+    np.testing.assert_allclose(q.sum(axis=1), 1.0, rtol=0, atol=1e-12)
+    off = np.concatenate([[0], np.cumsum(ua)])
+    sums = np.add.reduceat(p, off[:-1], axis=1)
+    np.testing.assert_allclose(sums, 1.0, rtol=0, atol=1e-12)
+
+
+def test_config2_full_size_against_oracle():
+    I, L, K = 2000, 20000, 5
+    ua, geno = make_dataset(I, L, K, ploidy=2, max_alleles=2, seed=20250119, chunk=128)
+    lb = ob.lib.mco_lower_bound(1e-8, I, 2)
+    q0, p0 = random_params(I, ua, K, seed=4, lower_bound=lb)
+    ctx = mc.Context(0)
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, lower_bound=lb)
+    ctx.set_q(0, q0)
+    ctx.set_p(0, p0)
+    opt = ob.make_options(lower_bound=lb, fused=1, abs_error=0.0)
+    mod = ob.Model(ob.Data(I, L, 2, ua, geno), opt, K)
+    mod.q(0)[...] = q0
+    mod.p(0)[...] = p0
+    prev = -np.inf
+    for s in range(3):
+        mod.em_step()
+        ll = ctx.em_step(0, 0)
+        # |logL| ~ 5e7: the reference's own sequential double sum is only good to ~1e-13 |logL| there
+        assert abs(ll - mod.logL) <= 1e-12 * abs(mod.logL), (s, ll, mod.logL)
+        assert ll > prev
+        prev = ll
+        q, p = ctx.get_q(0), ctx.get_p(0)
+        np.testing.assert_allclose(q, mod.q(0), rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(p, mod.p(0), rtol=1e-9, atol=1e-13)
+        # every allele copy is shared out over the K clusters: sum_k S_ik = number of observed copies of individual i
+        np.testing.assert_allclose(ctx.expected_counts().sum(axis=1), (geno != 255).sum(axis=(1, 2)), rtol=1e-13)
+        check_simplex(q, p, ua, lb)
+    ctx.close()
+
+
+def test_config3_full_size_properties_and_slice_against_oracle():
+    I, L, K = 10000, 100000, 8
+    ua, geno = fast_geno(I, L, 2, 4, seed=20250120)
+    T = int(ua.sum())
+    lb = ob.lib.mco_lower_bound(1e-8, I, 2)
+    q0, p0 = random_params(I, ua, K, seed=5, lower_bound=lb)
+    ctx = mc.Context(0)
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, lower_bound=lb, n_secants=1)
+    ctx.set_q(0, q0)
+    ctx.set_p(0, p0)
+    ll0 = ctx.em_step(0, 1)                                    # E(x0), M -> slot 1
+    sik = ctx.expected_counts()
+    np.testing.assert_allclose(sik.sum(axis=1), 2.0 * L, rtol=1e-13)       # no missing data: 2 L copies per individual
+    assert abs(sik.sum() - 2.0 * I * L) <= 1e-12 * 2.0 * I * L
+    # slice of individuals against the oracle: S_ik and q' of individual i depend on its own genotype, q_i and P only
+    sel = np.array([0, 1, 17, 4095, 4096, 5000, 9998, 9999])
+    opt = ob.make_options(lower_bound=lb, fused=1, abs_error=0.0)
+    mod = ob.Model(ob.Data(len(sel), L, 2, ua, geno[sel]), opt, K)
+    mod.q(0)[...] = q0[sel]
+    mod.p(0)[...] = p0
+    mod.em_step()
+    np.testing.assert_allclose(sik[sel], mod.sik(), rtol=1e-11, atol=1e-12)
+    q1, p1 = ctx.get_q(1), ctx.get_p(1)
+    np.testing.assert_allclose(q1[sel], mod.q(0), rtol=1e-10, atol=1e-14)
+    check_simplex(q1, p1, ua, lb)
+    # log likelihood: stand-alone pass = E-step value (same parameters), and EM increases it
+    assert ctx.loglik(0) == ll0
+    ll1 = ctx.em_step(1, 1)
+    assert ll1 > ll0
+    assert abs(ctx.loglik_prefetch(1) - ctx.loglik(1)) == 0.0
+    # linearity of the secant / dot kernels at full size
+    ctx.secant(0, 0, 1, 0)
+    ctx.secant(1, 0, 1, 0)
+    d = ctx.step_dots(0)                                       # v == u: u.(v-u) = 0, |v-u|^2 = 0
+    assert d[0] > 0 and d[1] == 0.0 and d[2] == 0.0
+    q2, p2 = ctx.get_q(1), ctx.get_p(1)                        # slot 1 now holds the second iterate
+    u2 = float(((q2 - q0) ** 2).sum() + ((p2 - p0) ** 2).sum())
+    assert abs(d[0] - u2) <= 1e-9 * u2
+    ctx.close()
