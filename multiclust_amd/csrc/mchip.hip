@@ -713,13 +713,14 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	}
 	/* log-product check interval: with every parameter >= its lower bound, t = sum_k q_k p_k >= p_lb / K, so
 	 * floor(200 / -log10(t_min)) multiplications keep a product that starts above 1e-100 above 1e-300
-	 * (DESIGN.md section 4).  A block of 8 individuals multiplies 8*ploidy times. */
+	 * (DESIGN.md section 4).  A block of 8 loci (or individuals) multiplies 8*ploidy times. */
 	{
 		const double tmin = p_lb / K;
 		int blocks = 0;
 		if (do_projection && tmin > 0 && tmin < 1) {
 			const double mults = floor(200.0 / -log10(tmin));
-			blocks = (int)(mults / (8.0 * ctx->ploidy));
+			/* the sparse tetraploid pass checks twice per block (every 4 loci = 16 multiplications) */
+			blocks = (int)(mults / (ctx->ploidy == 4 ? 16.0 : 8.0 * ctx->ploidy));
 			if (blocks > 1 << 16) blocks = 1 << 16;
 		}
 		ctx->flush_blocks = blocks;

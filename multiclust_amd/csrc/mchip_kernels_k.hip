@@ -376,6 +376,16 @@ constexpr int KP = (K + 1) & ~1;	/* LDS row stride in doubles: rows stay 16-byte
 #ifndef MCHIP_SPARSE_WAVES
 #define MCHIP_SPARSE_WAVES 1
 #endif
+/* Keeps a running product of t values away from underflow without a log in the loop: below 1e-100 its binary
+ * exponent moves into an integer (v_frexp_exp_i32_f64 / v_frexp_mant_f64); log(product) = ex*ln2 + log(prod). */
+__device__ __forceinline__ void rescale(double &prod, int &ex)
+{
+	if (prod < 1e-100) {
+		ex += __builtin_amdgcn_frexp_exp(prod);
+		prod = __builtin_amdgcn_frexp_mant(prod);
+	}
+}
+
 template <int PL, bool ACCUM, bool SAFE, bool NOMISS>
 __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_sparse(mchip_pass_args a)
 {
@@ -395,8 +405,8 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 	const int l0 = blockIdx.y * a.lchunk;
 	const int l1 = min(a.L, l0 + a.lchunk);
 	const int lb0 = l0 >> 3, lb_end = (l1 + 7) >> 3;
-	double ll = 0.0, prod = 1.0;
-	int blk = 0;
+	double prod = 1.0;
+	int blk = 0, ex = 0;
 
 	/* stage the first tile */
 	{
@@ -470,12 +480,7 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 						prod *= miss[b] ? 1.0 : t[b];
 						prod *= miss[b + 1] ? 1.0 : t[b + 1];
 					}
-					if (SAFE) {
-						if (prod < 1e-100) {
-							ll += log(prod);
-							prod = 1.0;
-						}
-					}
+					if (SAFE) rescale(prod, ex);
 				}
 			} else {
 				for (int bb = 0; bb < pl; bb++) {	/* any other ploidy: one copy at a time */
@@ -495,32 +500,37 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[k], r, acc[k]);
 					}
 					prod *= miss ? 1.0 : t;
-					if (prod < 1e-100) {
-						ll += log(prod);
-						prod = 1.0;
-					}
+					rescale(prod, ex);
+				}
+			}
+		};
+		/* !SAFE: the product is looked at every flush_blocks units of 16 multiplications: a block of 8 diploid loci,
+		 * half a block of tetraploid ones (the host sizes flush_blocks for that, mchip_set_model) */
+		auto tick = [&]() __attribute__((always_inline)) {
+			if (!SAFE) {
+				if (++blk >= a.flush_blocks) {
+					blk = 0;
+					rescale(prod, ex);
 				}
 			}
 		};
 		if (lb * 8 + 8 <= l1) {
 #pragma unroll
-			for (int j = 0; j < 8; j++) one_locus(j);
+			for (int j = 0; j < 8; j++) {
+				one_locus(j);
+				if (PL == 4 && j == 3) tick();
+			}
 		} else {
-			for (int j = 0; j < 8 && lb * 8 + j < l1; j++) one_locus(j);
-		}
-		if (!SAFE) {
-			if (++blk >= a.flush_blocks) {
-				blk = 0;
-				if (prod < 1e-100) {
-					ll += log(prod);
-					prod = 1.0;
-				}
+			for (int j = 0; j < 8 && lb * 8 + j < l1; j++) {
+				one_locus(j);
+				if (PL == 4 && j == 3) tick();
 			}
 		}
+		tick();
 		g = gn;
 		__syncthreads();	/* next tile is complete and this one may be overwritten */
 	}
-	ll += log(prod);
+	const double ll = (double)ex * 0.693147180559945309417 + log(prod);
 	if (ACCUM && active) {
 		double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
 #pragma unroll
