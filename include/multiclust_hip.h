@@ -123,6 +123,15 @@ int mchip_loglik_prefetch(mchip_context *ctx, int slot, double *loglik);
  * allele copy a (the host draws it with the libc-compatible stream); d_iklm = 1 (not += 1) per matching copy.
  */
 int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to);
+/*
+ * The same with the partition drawn on the device: assign[j] = rand() % K for j = 0 .. I*L*ploidy-1 in the
+ * reference's i, l, a order (rnd_init.c:456-467), where rand() is glibc's TYPE_3 generator
+ * x_j = x_{j-31} + x_{j-3} (mod 2^32), rand() = x_j >> 1, and window[t] = x_{j0-31+t}, t = 0..30, are the 31 words
+ * behind the first draw (oldest first; the host's generator state after srand() and any draws made so far).  The
+ * caller advances its own copy of the stream by I*L*ploidy draws.  Bit-identical to drawing on the host and
+ * calling mchip_mstep_from_partition; removes I*L*ploidy host rand() calls and the upload per initialisation.
+ */
+int mchip_mstep_from_rand_partition(mchip_context *ctx, const uint32_t *window, int to);
 
 /*
  * What the writers read from diklm / vik (write_file.c:359-381,446-459,531-542,593-598):

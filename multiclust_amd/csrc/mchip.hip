@@ -46,6 +46,9 @@ struct mchip_context {
 	int count_bits, has_missing;
 	size_t geno_bytes_A, geno_bytes_S;
 	uint8_t *d_asA, *d_asS;		/* hard-partition scratch, allocated on first use */
+	uint8_t *d_draw;		/* device-drawn partition in stream order [I][L][ploidy], padded to whole chunks */
+	uint32_t *d_jump_hi, *d_jump_lo;	/* jump polynomials of the rand() stream (mchip_mstep_from_rand_partition) */
+	size_t n_jump_hi;
 	/* model */
 	int K, admixture, constrained, do_projection, nsec, nq, qstride;
 	double eta_lb, p_lb;
@@ -128,6 +131,72 @@ __global__ void k_relayout(const uint8_t *__restrict__ raw, int I, int L, int pl
 		const size_t lb = r / I;
 		const size_t l = lb * 8 + j;
 		gtS[idx] = (l < (size_t)L) ? raw[(i * L + l) * pl + a] : (uint8_t)0xFF;
+	}
+}
+
+/* ------------------------------------------------------------------ libc-compatible rand() on the device
+ * glibc's TYPE_3 generator is the additive lagged Fibonacci recurrence x_j = x_{j-31} + x_{j-3} (mod 2^32) with
+ * rand() = x_j >> 1.  It is linear, so x^n mod (x^31 - x^28 - 1) over Z/2^32 carries a 31-word window n draws
+ * ahead.  Thread c draws the RNG_CHUNK consecutive values that start RNG_CHUNK*c draws into the stream: its jump
+ * polynomial is the product of two tabulated ones (hi = c / 256, lo = c % 256), so the stream is the serial one
+ * whatever the launch geometry (random_allele_partition, rnd_init.c:456-467: one rand() % K per allele copy). */
+constexpr int RNG_LAG = 31;
+constexpr int RNG_CHUNK = 4 * RNG_LAG * 32;	/* draws (= bytes written) per thread: 32 rounds of 31 packed words */
+
+struct rng_window { uint32_t s[2 * RNG_LAG - 1]; };	/* x_{j-31} .. x_{j+29}: window, then its next 30 values */
+
+__global__ __launch_bounds__(256) void k_draw_partition(rng_window base, const uint32_t *__restrict__ jump_hi,
+		const uint32_t *__restrict__ jump_lo, size_t n_chunks, uint32_t K, uint32_t magic, uint32_t shift, uint32_t *out)
+{
+	const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (c >= n_chunks) return;
+	/* jump polynomial = hi(x) * lo(x) mod (x^31 - x^28 - 1); hi is block-uniform (scalar loads), lo is stored
+	 * [31][256] so that lanes read consecutive words */
+	uint32_t t[2 * RNG_LAG - 1];
+#pragma unroll
+	for (int d = 0; d < 2 * RNG_LAG - 1; d++) t[d] = 0;
+	{
+		uint32_t lo[RNG_LAG];
+#pragma unroll
+		for (int j = 0; j < RNG_LAG; j++) lo[j] = jump_lo[j * 256 + threadIdx.x];
+		const uint32_t *hi = jump_hi + (size_t)blockIdx.x * RNG_LAG;
+#pragma unroll
+		for (int i = 0; i < RNG_LAG; i++) {
+			const uint32_t h = hi[i];
+#pragma unroll
+			for (int j = 0; j < RNG_LAG; j++) t[i + j] += h * lo[j];
+		}
+#pragma unroll
+		for (int d = 2 * RNG_LAG - 2; d >= RNG_LAG; d--) {	/* x^d = x^(d-3) + x^(d-31) */
+			t[d - 3] += t[d];
+			t[d - RNG_LAG] += t[d];
+		}
+	}
+	/* window at this thread's first draw: w[e] = sum_j poly[j] * s[e + j] */
+	uint32_t w[RNG_LAG];
+#pragma unroll
+	for (int e = 0; e < RNG_LAG; e++) {
+		uint32_t v = 0;
+#pragma unroll
+		for (int j = 0; j < RNG_LAG; j++) v += t[j] * base.s[e + j];
+		w[e] = v;
+	}
+	uint32_t *dst = out + c * (RNG_CHUNK / 4);
+	for (int round = 0; round < RNG_CHUNK / (4 * RNG_LAG); round++) {
+		uint32_t word[RNG_LAG];
+#pragma unroll
+		for (int d = 0; d < 4 * RNG_LAG; d++) {
+			const int e = d % RNG_LAG;
+			const uint32_t x = w[e] + w[(e + RNG_LAG - 3) % RNG_LAG];	/* x_{j-31} + x_{j-3} */
+			w[e] = x;
+			const uint32_t v = x >> 1;
+			/* v % K by multiplication: floor(v / K) = (v * magic) >> (31 + ceil(log2 K)), exact for v < 2^31 */
+			const uint32_t r = v - (__umulhi(v, magic) >> shift) * K;
+			if (d % 4 == 0) word[d / 4] = r;
+			else word[d / 4] |= r << (8 * (d % 4));
+		}
+#pragma unroll
+		for (int x = 0; x < RNG_LAG; x++) dst[round * RNG_LAG + x] = word[x];
 	}
 }
 
@@ -446,6 +515,8 @@ static void free_data(mchip_context *ctx)
 {
 	dfree(ctx->d_ua); dfree(ctx->d_toff); dfree(ctx->d_col_locus); dfree(ctx->d_col_allele);
 	dfree(ctx->d_gtA); dfree(ctx->d_gtS); dfree(ctx->d_gtC); dfree(ctx->d_asA); dfree(ctx->d_asS);
+	dfree(ctx->d_draw); dfree(ctx->d_jump_hi); dfree(ctx->d_jump_lo);
+	ctx->n_jump_hi = 0;
 	ctx->I = ctx->L = ctx->T = 0;
 }
 
@@ -993,22 +1064,14 @@ int mchip_loglik_prefetch(mchip_context *ctx, int slot, double *loglik)
 	return MCHIP_OK;
 }
 
-int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to)
+/* relayout of a partition held on the device in stream order, then the hard-partition M step into slot `to` */
+static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to)
 {
-	int rc = check_slot(ctx, to);
-	if (rc) return rc;
-	ctx->s_cache_slot = -1;
-	if (!assign) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
-	if (!ctx->admixture) return fail(ctx, MCHIP_ERR_STATE, "allele partitions initialise the admixture model only%s", nullptr);
-	HIPCHK(hipSetDevice(ctx->device));
-	const size_t raw_bytes = (size_t)ctx->I * ctx->L * ctx->ploidy;
+	int rc;
 	if (!ctx->d_asA) HIPCHK(hipMalloc((void **)&ctx->d_asA, ctx->geno_bytes_A));
 	if (!ctx->d_asS) HIPCHK(hipMalloc((void **)&ctx->d_asS, ctx->geno_bytes_S));
-	uint8_t *d_raw = nullptr;
 	int *d_bad = nullptr;
-	HIPCHK(hipMalloc((void **)&d_raw, raw_bytes));
 	HIPCHK(hipMalloc((void **)&d_bad, sizeof(int)));
-	HIPCHK(hipMemcpyAsync(d_raw, assign, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
 	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_raw, ctx->I, ctx->L, ctx->ploidy,
@@ -1017,7 +1080,6 @@ int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
-	(void)hipFree(d_raw);
 	(void)hipFree(d_bad);
 	if (bad) return fail(ctx, MCHIP_ERR_INVALID, "partition assignment >= K%s", nullptr);
 
@@ -1034,6 +1096,108 @@ int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	return MCHIP_OK;
+}
+
+static int check_partition_call(mchip_context *ctx, const void *arg, int to)
+{
+	int rc = check_slot(ctx, to);
+	if (rc) return rc;
+	ctx->s_cache_slot = -1;
+	if (!arg) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
+	if (!ctx->admixture) return fail(ctx, MCHIP_ERR_STATE, "allele partitions initialise the admixture model only%s", nullptr);
+	return MCHIP_OK;
+}
+
+int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to)
+{
+	int rc = check_partition_call(ctx, assign, to);
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t raw_bytes = (size_t)ctx->I * ctx->L * ctx->ploidy;
+	uint8_t *d_raw = nullptr;
+	HIPCHK(hipMalloc((void **)&d_raw, raw_bytes));
+	HIPCHK(hipMemcpyAsync(d_raw, assign, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
+	rc = partition_mstep(ctx, d_raw, to);
+	(void)hipFree(d_raw);
+	return rc;
+}
+
+/* (a * b) mod (x^31 - x^28 - 1) over Z/2^32 */
+static void rng_polymul(const uint32_t *a, const uint32_t *b, uint32_t *out)
+{
+	uint32_t t[2 * RNG_LAG - 1] = {0};
+	for (int i = 0; i < RNG_LAG; i++)
+		for (int j = 0; j < RNG_LAG; j++) t[i + j] += a[i] * b[j];
+	for (int d = 2 * RNG_LAG - 2; d >= RNG_LAG; d--) {
+		t[d - 3] += t[d];
+		t[d - RNG_LAG] += t[d];
+	}
+	memcpy(out, t, RNG_LAG * sizeof(uint32_t));
+}
+
+/* tables of x^(lo*CHUNK), lo < 256 (stored [31][256]) and x^(hi*256*CHUNK), hi < n_hi (stored [n_hi][31]) */
+static int rng_jump_tables(mchip_context *ctx, size_t n_hi)
+{
+	if (ctx->d_jump_lo && ctx->n_jump_hi >= n_hi) return MCHIP_OK;
+	dfree(ctx->d_jump_hi);
+	dfree(ctx->d_jump_lo);
+	ctx->n_jump_hi = 0;
+	uint32_t step[RNG_LAG] = {0}, sq[RNG_LAG] = {0}, cur[RNG_LAG];
+	step[0] = 1;	/* x^0 */
+	sq[1] = 1;	/* x^1 */
+	for (unsigned e = RNG_CHUNK; e; e >>= 1) {	/* step = x^CHUNK */
+		if (e & 1) rng_polymul(step, sq, step);
+		rng_polymul(sq, sq, sq);
+	}
+	std::vector<uint32_t> lo((size_t)RNG_LAG * 256), hi(n_hi * RNG_LAG);
+	memset(cur, 0, sizeof cur);
+	cur[0] = 1;
+	for (int x = 0; x < 256; x++) {
+		for (int j = 0; j < RNG_LAG; j++) lo[(size_t)j * 256 + x] = cur[j];
+		rng_polymul(cur, step, cur);
+	}
+	memcpy(step, cur, sizeof step);	/* x^(256*CHUNK) */
+	memset(cur, 0, sizeof cur);
+	cur[0] = 1;
+	for (size_t x = 0; x < n_hi; x++) {
+		memcpy(&hi[x * RNG_LAG], cur, sizeof cur);
+		rng_polymul(cur, step, cur);
+	}
+	HIPCHK(hipMalloc((void **)&ctx->d_jump_lo, lo.size() * sizeof(uint32_t)));
+	HIPCHK(hipMalloc((void **)&ctx->d_jump_hi, hi.size() * sizeof(uint32_t)));
+	HIPCHK(hipMemcpy(ctx->d_jump_lo, lo.data(), lo.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(ctx->d_jump_hi, hi.data(), hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	ctx->n_jump_hi = n_hi;
+	return MCHIP_OK;
+}
+
+int mchip_mstep_from_rand_partition(mchip_context *ctx, const uint32_t *window, int to)
+{
+	int rc = check_partition_call(ctx, window, to);
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
+	const size_t n_chunks = (n + RNG_CHUNK - 1) / RNG_CHUNK;
+	const size_t n_blocks = (n_chunks + 255) / 256;
+	if (!ctx->d_draw) HIPCHK(hipMalloc((void **)&ctx->d_draw, n_chunks * RNG_CHUNK));
+	if (ctx->K == 1) {
+		HIPCHK(hipMemsetAsync(ctx->d_draw, 0, n, ctx->stream));	/* rand() % 1 */
+	} else {
+		if ((rc = rng_jump_tables(ctx, n_blocks))) return rc;
+		rng_window base;
+		for (int t = 0; t < RNG_LAG; t++) base.s[t] = window[t];
+		for (int t = 0; t < RNG_LAG - 1; t++) base.s[RNG_LAG + t] = base.s[t] + base.s[RNG_LAG - 3 + t];
+		/* v % K through floor(v / K) = (v * magic) >> (31 + l), l = ceil(log2 K), magic = ceil(2^(31+l) / K) < 2^32:
+		 * exact for every v < 2^31 (division by an invariant integer); the kernel takes the high word, so shift = l - 1 */
+		uint32_t l = 0;
+		while ((1u << l) < (uint32_t)ctx->K) l++;
+		const uint64_t pw = (uint64_t)1 << (31 + l);
+		const uint32_t magic = (uint32_t)((pw + (uint64_t)ctx->K - 1) / (uint64_t)ctx->K);
+		hipLaunchKernelGGL(k_draw_partition, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, base, ctx->d_jump_hi,
+				   ctx->d_jump_lo, n_chunks, (uint32_t)ctx->K, magic, l - 1, (uint32_t *)ctx->d_draw);
+		HIPCHK(hipGetLastError());
+	}
+	return partition_mstep(ctx, ctx->d_draw, to);
 }
 
 int mchip_get_expected_counts(mchip_context *ctx, double *sik)

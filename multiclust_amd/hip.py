@@ -60,6 +60,7 @@ def load():
         "mchip_loglik": ([vp, i32, dp], i32),
         "mchip_loglik_prefetch": ([vp, i32, dp], i32),
         "mchip_mstep_from_partition": ([vp, vp, i32], i32),
+        "mchip_mstep_from_rand_partition": ([vp, vp, i32], i32),
         "mchip_get_expected_counts": ([vp, vp], i32),
         "mchip_secant": ([vp, i32, i32, i32, i32], i32),
         "mchip_step_dots": ([vp, i32, dp], i32),
@@ -86,7 +87,8 @@ ABI_SYMBOLS = [
     "mchip_abi_version", "mchip_device_count", "mchip_create", "mchip_destroy", "mchip_last_error",
     "mchip_synchronize", "mchip_set_genotypes", "mchip_set_model", "mchip_set_p", "mchip_get_p", "mchip_set_q",
     "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_em_run", "mchip_last_loglik", "mchip_e_step",
-    "mchip_loglik", "mchip_loglik_prefetch", "mchip_mstep_from_partition", "mchip_get_expected_counts", "mchip_secant", "mchip_step_dots",
+    "mchip_loglik", "mchip_loglik_prefetch", "mchip_mstep_from_partition", "mchip_mstep_from_rand_partition",
+    "mchip_get_expected_counts", "mchip_secant", "mchip_step_dots",
     "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
     "mchip_profile_end", "mchip_device_info", "mchip_comm_create", "mchip_comm_all_reduce", "mchip_comm_destroy",
     "mchip_comm_last_error",
@@ -188,6 +190,12 @@ class Context:
         a = np.ascontiguousarray(assign, dtype=np.uint8)
         assert a.size == self.I * self.L * self.ploidy
         self._chk(self.lib.mchip_mstep_from_partition(self.h, a.ctypes.data, to))
+
+    def mstep_from_rand_partition(self, window, to=0):
+        """window: the 31 uint32 words behind the first draw, oldest first (see include/multiclust_hip.h)."""
+        w = np.ascontiguousarray(window, dtype=np.uint32)
+        assert w.size == 31
+        self._chk(self.lib.mchip_mstep_from_rand_partition(self.h, w.ctypes.data, to))
 
     def expected_counts(self):
         s = np.empty((self.I, self.K), dtype=np.float64)

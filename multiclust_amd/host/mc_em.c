@@ -288,6 +288,15 @@ int mc_initialize_model(const mc_options *opt, const mc_data *dat, mc_model *mod
 	if (opt->accel_scheme) mod->pindex = mod->tindex = mod->findex = 0;
 	if (!opt->admixture)
 		return dev_fail(mod, initialize_mixture(dat, mod, rng), "mc_initialize_model");
+	if (!getenv("MC_HOST_INIT")) {
+		/* the partition is drawn on the device from this point of the stream; the host copy of the stream moves on
+		 * by the same number of draws */
+		uint32_t window[31];
+		for (int t = 0; t < 31; t++) window[t] = (uint32_t)rng->r[(rng->f + t) % 31];
+		rc = mchip_mstep_from_rand_partition(mod->dev, window, mod->tindex);
+		mc_rng_jump(rng, (uint64_t)n);
+		return dev_fail(mod, rc, "mc_initialize_model");
+	}
 	if (!(assign = malloc(n))) return MCHIP_ERR_ALLOC;
 	draw_partition(assign, n, mod->K, rng);
 	rc = mchip_mstep_from_partition(mod->dev, assign, mod->tindex);

@@ -196,6 +196,22 @@ def michelot(x, minimum, total=1.0):
     return x
 
 
+def glibc_window(seed, skip=0):
+    """The 31 words behind draw number `skip` of the stream srand(seed) starts, oldest first, and the next n draws'
+    generator (for mchip_mstep_from_rand_partition)."""
+    rng = Rng()
+    lib.mco_srand(C.byref(rng), seed)
+    for _ in range(skip):
+        lib.mco_rand(C.byref(rng))
+    window = np.array([rng.r[(rng.f + t) % 31] for t in range(31)], dtype=np.int64).astype(np.uint32)
+    return window, rng
+
+
+def rand_mod(rng, n, K):
+    """n draws of rand() % K from the oracle's generator (a C loop would be faster; n is small in tests)."""
+    return np.fromiter((lib.mco_rand(C.byref(rng)) % K for _ in range(n)), dtype=np.uint8, count=n)
+
+
 def glibc_rand(seed, n):
     rng = Rng()
     lib.mco_srand(C.byref(rng), seed)

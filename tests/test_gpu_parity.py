@@ -77,6 +77,46 @@ def test_first_mstep_from_partition_same_seed(ctx, name):
     close(ctx.get_p(0), g.p("p0"), 1e-15, 1e-18)
 
 
+@pytest.mark.parametrize("name", ADMIX)
+def test_first_mstep_partition_drawn_on_device(ctx, name):
+    """The same with the rand() stream generated on the device (mchip_mstep_from_rand_partition): the reference's
+    own initial parameters for its seed."""
+    g = Golden(name)
+    ctx.set_genotypes(g.ua, g.geno)
+    ctx.set_model(g.K, lower_bound=g.lower_bound)
+    window, _ = ob.glibc_window(g.m["seed"])
+    ctx.mstep_from_rand_partition(window, 0)
+    assert np.array_equal(ctx.expected_counts(), g.sik("init"))
+    close(ctx.get_q(0), g.q("q0"), 1e-15, 1e-18)
+    close(ctx.get_p(0), g.p("p0"), 1e-15, 1e-18)
+
+
+@pytest.mark.parametrize("I,L,ploidy,K,skip", [
+    (700, 1000, 2, 8, 0),        # 1.4e6 draws: more than one block of 256 chunks (both jump tables used)
+    (301, 997, 4, 3, 1234),      # ragged tail chunk, stream already advanced, K not a power of two
+    (513, 640, 2, 32, 77),       # K = 32
+    (129, 400, 3, 7, 5),         # odd ploidy
+    (64, 100, 2, 1, 0),          # K = 1: rand() % 1
+    (900, 900, 2, 2, 31),
+])
+def test_device_draw_equals_host_draw(ctx, I, L, ploidy, K, skip):
+    """Bit-identical initial Q, P and per-individual counts whether the partition is drawn on the host from the
+    libc-compatible stream and uploaded, or generated on the device from the stream's 31-word window."""
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=4, seed=I + K, missing=0.01)
+    lb = ob.lib.mco_lower_bound(1e-8, I, ploidy)
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, lower_bound=lb)
+    window, rng = ob.glibc_window(20250117, skip)
+    assign = ob.rand_mod(rng, I * L * ploidy, K)
+    ctx.mstep_from_partition(assign, 0)
+    ctx.mstep_from_rand_partition(window, 1)
+    sik_dev = ctx.expected_counts()
+    ctx.mstep_from_partition(assign, 2)
+    assert np.array_equal(ctx.expected_counts(), sik_dev)
+    assert np.array_equal(ctx.get_q(0), ctx.get_q(1))
+    assert np.array_equal(ctx.get_p(0), ctx.get_p(1))
+
+
 @pytest.mark.parametrize("I,L,K,ploidy,maxal,missing", [
     (300, 1000, 8, 2, 4, 0.0),       # config-3 shape, small
     (257, 999, 5, 2, 2, 0.02),       # ragged sizes (not multiples of 8 / 64 / 256), missing data
