@@ -59,6 +59,19 @@ int mchip_synchronize(mchip_context *ctx);
  */
 int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy,
 			const int32_t *uniquealleles, const uint8_t *geno);
+/* the data set currently held, back in the upload form [I][L][ploidy] */
+int mchip_get_genotypes(mchip_context *ctx, uint8_t *geno);
+/*
+ * A parametric-bootstrap data set generated on the device instead of uploaded: parametric_bootstrap_admixture
+ * (bootstrap.c:84-124).  Same shape arguments as mchip_set_genotypes; allele copy j (i, l, n order) uses draws 2j and
+ * 2j+1 of the rand() stream described by `window` (see mchip_mstep_from_rand_partition): source cluster by the
+ * inverse-CDF walk over q[i][.] (or q[.] when eta_constrained), then the allele by the walk over p[k][l][.], with
+ * r = rand() / RAND_MAX and the reference's left-to-right partial sums.  q is [I][K] (or [K]), p is [K][T] (the H0
+ * MLEs, multiclust.c:562-581).  Consumes 2*I*L*ploidy draws; every copy is simulated, as in the reference's default
+ * build.  Like mchip_set_genotypes it drops any model: call mchip_set_model next.
+ */
+int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int32_t *uniquealleles,
+			     const uint32_t *window, int K, int eta_constrained, const double *q, const double *p);
 
 /*
  * Allocate parameter ring, secant buffers and workspaces for K.  Replaces allocate_model_for_k

@@ -145,13 +145,12 @@ constexpr int RNG_CHUNK = 4 * RNG_LAG * 32;	/* draws (= bytes written) per threa
 
 struct rng_window { uint32_t s[2 * RNG_LAG - 1]; };	/* x_{j-31} .. x_{j+29}: window, then its next 30 values */
 
-__global__ __launch_bounds__(256) void k_draw_partition(rng_window base, const uint32_t *__restrict__ jump_hi,
-		const uint32_t *__restrict__ jump_lo, size_t n_chunks, uint32_t K, uint32_t magic, uint32_t shift, uint32_t *out)
+/* window (31 words behind the first draw) of the thread whose chunk starts 256*hi_index + threadIdx.x chunks into the
+ * stream: jump polynomial = hi(x) * lo(x) mod (x^31 - x^28 - 1); hi is block-uniform (scalar loads), lo is stored
+ * [31][256] so that lanes read consecutive words */
+__device__ __forceinline__ void rng_thread_window(const rng_window &base, const uint32_t *__restrict__ jump_hi,
+		const uint32_t *__restrict__ jump_lo, uint32_t (&w)[RNG_LAG])
 {
-	const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (c >= n_chunks) return;
-	/* jump polynomial = hi(x) * lo(x) mod (x^31 - x^28 - 1); hi is block-uniform (scalar loads), lo is stored
-	 * [31][256] so that lanes read consecutive words */
 	uint32_t t[2 * RNG_LAG - 1];
 #pragma unroll
 	for (int d = 0; d < 2 * RNG_LAG - 1; d++) t[d] = 0;
@@ -172,8 +171,7 @@ __global__ __launch_bounds__(256) void k_draw_partition(rng_window base, const u
 			t[d - RNG_LAG] += t[d];
 		}
 	}
-	/* window at this thread's first draw: w[e] = sum_j poly[j] * s[e + j] */
-	uint32_t w[RNG_LAG];
+	/* w[e] = sum_j poly[j] * s[e + j] */
 #pragma unroll
 	for (int e = 0; e < RNG_LAG; e++) {
 		uint32_t v = 0;
@@ -181,6 +179,15 @@ __global__ __launch_bounds__(256) void k_draw_partition(rng_window base, const u
 		for (int j = 0; j < RNG_LAG; j++) v += t[j] * base.s[e + j];
 		w[e] = v;
 	}
+}
+
+__global__ __launch_bounds__(256) void k_draw_partition(rng_window base, const uint32_t *__restrict__ jump_hi,
+		const uint32_t *__restrict__ jump_lo, size_t n_chunks, uint32_t K, uint32_t magic, uint32_t shift, uint32_t *out)
+{
+	const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (c >= n_chunks) return;
+	uint32_t w[RNG_LAG];
+	rng_thread_window(base, jump_hi, jump_lo, w);
 	uint32_t *dst = out + c * (RNG_CHUNK / 4);
 	for (int round = 0; round < RNG_CHUNK / (4 * RNG_LAG); round++) {
 		uint32_t word[RNG_LAG];
@@ -198,6 +205,83 @@ __global__ __launch_bounds__(256) void k_draw_partition(rng_window base, const u
 #pragma unroll
 		for (int x = 0; x < RNG_LAG; x++) dst[round * RNG_LAG + x] = word[x];
 	}
+}
+
+/* parametric_bootstrap_admixture (bootstrap.c:84-124) on the device.  Allele copy j (i, l, n order) takes draws 2j
+ * (source cluster: inverse-CDF walk over the individual's eta) and 2j+1 (allele: walk over p[k][l][.]) of the rand()
+ * stream, r = rand() / RAND_MAX in double and the same left-to-right partial sums, so the decisions are the
+ * reference's.  Every copy is simulated (in the default build the "missing stays missing" count is overwritten before
+ * it is used, bootstrap.c:87-96).  Thread c owns RNG_CHUNK consecutive draws = RNG_CHUNK/2 copies; its generator
+ * window lives in LDS ([31][256]: word e of all lanes is one conflict-free row) so the loop stays compact. */
+__global__ __launch_bounds__(256) void k_simulate_admixture(rng_window base, const uint32_t *__restrict__ jump_hi,
+		const uint32_t *__restrict__ jump_lo, size_t n_chunks, size_t n_copies, int L, int pl, int K, int T,
+		const int32_t *__restrict__ toff, const double *__restrict__ q, int qstride, const double *__restrict__ p,
+		uint32_t *out)
+{
+	__shared__ uint32_t ring[RNG_LAG * 256];
+	const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (c >= n_chunks) return;
+	{
+		uint32_t w[RNG_LAG];
+		rng_thread_window(base, jump_hi, jump_lo, w);
+#pragma unroll
+		for (int e = 0; e < RNG_LAG; e++) ring[e * 256 + threadIdx.x] = w[e];
+	}
+	int e = 0;
+	auto next = [&]() -> double {
+		const int e3 = e >= 3 ? e - 3 : e + RNG_LAG - 3;
+		const uint32_t x = ring[e * 256 + threadIdx.x] + ring[e3 * 256 + threadIdx.x];	/* x_{j-31} + x_{j-3} */
+		ring[e * 256 + threadIdx.x] = x;
+		e = e + 1 == RNG_LAG ? 0 : e + 1;
+		return (double)(x >> 1) / 2147483647.0;		/* rand() / RAND_MAX */
+	};
+	constexpr int COPIES = RNG_CHUNK / 2;
+	size_t j = c * COPIES;
+	const size_t per_i = (size_t)L * pl;
+	size_t i = j / per_i;
+	int l = (int)((j % per_i) / pl), a = (int)(j % pl);
+	uint32_t *dst = out + c * (COPIES / 4);
+	for (int x = 0; x < COPIES / 4; x++) {
+		uint32_t word = 0;
+		for (int y = 0; y < 4; y++) {
+			const double r1 = next();
+			const double r2 = next();
+			unsigned m = 0;
+			if (j < n_copies) {
+				const double *qi = q + i * (size_t)qstride;
+				int k = 0;
+				double sum = 0;
+				while (k < K && r1 > sum) sum += qi[k++];
+				if (k) k--;
+				const int c0 = toff[l], M = toff[l + 1] - c0;
+				const double *pk = p + (size_t)k * T + c0;
+				int mm = 0;
+				sum = 0;
+				while (mm < M && r2 > sum) sum += pk[mm++];
+				if (mm) mm--;
+				m = (unsigned)mm;
+			}
+			word |= m << (8 * y);
+			j++;
+			if (++a == pl) {
+				a = 0;
+				if (++l == L) { l = 0; i++; }
+			}
+		}
+		dst[x] = word;
+	}
+}
+
+/* gtA -> raw [I][L][pl] (mchip_get_genotypes) */
+__global__ void k_unlayout(const uint8_t *__restrict__ gtA, int I, int L, int pl, uint8_t *raw)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= (size_t)I * L * pl) return;
+	size_t r = idx;
+	const int a = (int)(r % pl); r /= pl;
+	const int l = (int)(r % L);
+	const size_t i = r / L;
+	raw[idx] = gtA[(((i >> 3) * L + l) * 8 + (i & 7)) * (size_t)pl + a];
 }
 
 /* gtA -> packed counts gtC[g][c]: thread = (group g of G individuals, column c) */
@@ -615,10 +699,10 @@ int mchip_device_info(mchip_context *ctx, char *name, int name_len, int *compute
 	return MCHIP_OK;
 }
 
-int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, const uint8_t *geno)
+/* shape of a data set: tables derived from uniquealleles, genotype buffers allocated but not filled */
+static int set_shape(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua)
 {
-	if (!ctx) return MCHIP_ERR_INVALID;
-	if (I <= 0 || L <= 0 || ploidy <= 0 || ploidy > 64 || !ua || !geno)
+	if (I <= 0 || L <= 0 || ploidy <= 0 || ploidy > 64 || !ua)
 		return fail(ctx, MCHIP_ERR_INVALID, "set_genotypes: bad shape or null pointer%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -645,24 +729,28 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 			col_allele[toff[l] + m] = (uint8_t)m;
 		}
 	ctx->I = I; ctx->L = L; ctx->ploidy = ploidy; ctx->T = T; ctx->max_M = maxM;
-	const size_t raw_bytes = (size_t)I * L * ploidy;
 	ctx->geno_bytes_A = (size_t)((I + 7) / 8) * L * 8 * ploidy;
 	ctx->geno_bytes_S = (size_t)((L + 7) / 8) * I * 8 * ploidy;
-	uint8_t *d_raw = nullptr;
-	int *d_bad = nullptr;
 	HIPCHK(hipMalloc((void **)&ctx->d_ua, sizeof(int32_t) * L));
 	HIPCHK(hipMalloc((void **)&ctx->d_toff, sizeof(int32_t) * (L + 9)));
 	HIPCHK(hipMalloc((void **)&ctx->d_col_locus, sizeof(int32_t) * T));
 	HIPCHK(hipMalloc((void **)&ctx->d_col_allele, T));
 	HIPCHK(hipMalloc((void **)&ctx->d_gtA, ctx->geno_bytes_A));
 	HIPCHK(hipMalloc((void **)&ctx->d_gtS, ctx->geno_bytes_S));
-	HIPCHK(hipMalloc((void **)&d_raw, raw_bytes));
-	HIPCHK(hipMalloc((void **)&d_bad, sizeof(int)));
 	HIPCHK(hipMemcpyAsync(ctx->d_ua, ua, sizeof(int32_t) * L, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(ctx->d_toff, toff.data(), sizeof(int32_t) * (L + 9), hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(ctx->d_col_locus, col_locus.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(ctx->d_col_allele, col_allele.data(), T, hipMemcpyHostToDevice, ctx->stream));
-	HIPCHK(hipMemcpyAsync(d_raw, geno, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));	/* the host vectors go out of scope */
+	return MCHIP_OK;
+}
+
+/* genotype held on the device as [I][L][ploidy] bytes -> the kernels' layouts (validated), packed counts */
+static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
+{
+	const int I = ctx->I, L = ctx->L, ploidy = ctx->ploidy, T = ctx->T;
+	int *d_bad = nullptr;
+	HIPCHK(hipMalloc((void **)&d_bad, sizeof(int)));
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
 	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_raw, I, L, ploidy, ctx->d_ua, 0,
@@ -671,7 +759,6 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
-	(void)hipFree(d_raw);
 	(void)hipFree(d_bad);
 	if (bad & 1) {
 		free_data(ctx);
@@ -684,7 +771,7 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	if (ctx->count_bits) {
 		const int G = 128 / ctx->count_bits;
 		const size_t nwords = (size_t)((I + G - 1) / G) * T;
-		HIPCHK(hipMalloc((void **)&ctx->d_gtC, nwords * 16));
+		if (!ctx->d_gtC) HIPCHK(hipMalloc((void **)&ctx->d_gtC, nwords * 16));
 		if (ctx->count_bits == 2)
 			hipLaunchKernelGGL(k_build_counts<2>, dim3(nblk(nwords)), dim3(256), 0, ctx->stream, ctx->d_gtA, I, L, ploidy, T,
 					   ctx->d_col_locus, ctx->d_col_allele, (uint4 *)ctx->d_gtC);
@@ -694,6 +781,37 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipStreamSynchronize(ctx->stream));
 	}
+	return MCHIP_OK;
+}
+
+int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, const uint8_t *geno)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	if (!geno) return fail(ctx, MCHIP_ERR_INVALID, "set_genotypes: bad shape or null pointer%s", nullptr);
+	int rc = set_shape(ctx, I, L, ploidy, ua);
+	if (rc) return rc;
+	const size_t raw_bytes = (size_t)I * L * ploidy;
+	uint8_t *d_raw = nullptr;
+	HIPCHK(hipMalloc((void **)&d_raw, raw_bytes));
+	HIPCHK(hipMemcpyAsync(d_raw, geno, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
+	rc = install_raw(ctx, d_raw);
+	(void)hipFree(d_raw);
+	return rc;
+}
+
+int mchip_get_genotypes(mchip_context *ctx, uint8_t *geno)
+{
+	if (!ctx || !geno) return MCHIP_ERR_INVALID;
+	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "no genotypes set%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
+	uint8_t *d_raw = nullptr;
+	HIPCHK(hipMalloc((void **)&d_raw, n));
+	hipLaunchKernelGGL(k_unlayout, dim3(nblk(n)), dim3(256), 0, ctx->stream, ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, d_raw);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(geno, d_raw, n, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	(void)hipFree(d_raw);
 	return MCHIP_OK;
 }
 
@@ -1171,22 +1289,28 @@ static int rng_jump_tables(mchip_context *ctx, size_t n_hi)
 	return MCHIP_OK;
 }
 
+static int rng_stream_setup(mchip_context *ctx, const uint32_t *window, size_t n_draws, rng_window *base, size_t *n_chunks, size_t *n_blocks)
+{
+	*n_chunks = (n_draws + RNG_CHUNK - 1) / RNG_CHUNK;
+	*n_blocks = (*n_chunks + 255) / 256;
+	for (int t = 0; t < RNG_LAG; t++) base->s[t] = window[t];
+	for (int t = 0; t < RNG_LAG - 1; t++) base->s[RNG_LAG + t] = base->s[t] + base->s[RNG_LAG - 3 + t];
+	return rng_jump_tables(ctx, *n_blocks);
+}
+
 int mchip_mstep_from_rand_partition(mchip_context *ctx, const uint32_t *window, int to)
 {
 	int rc = check_partition_call(ctx, window, to);
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
-	const size_t n_chunks = (n + RNG_CHUNK - 1) / RNG_CHUNK;
-	const size_t n_blocks = (n_chunks + 255) / 256;
+	rng_window base;
+	size_t n_chunks, n_blocks;
+	if ((rc = rng_stream_setup(ctx, window, n, &base, &n_chunks, &n_blocks))) return rc;
 	if (!ctx->d_draw) HIPCHK(hipMalloc((void **)&ctx->d_draw, n_chunks * RNG_CHUNK));
 	if (ctx->K == 1) {
 		HIPCHK(hipMemsetAsync(ctx->d_draw, 0, n, ctx->stream));	/* rand() % 1 */
 	} else {
-		if ((rc = rng_jump_tables(ctx, n_blocks))) return rc;
-		rng_window base;
-		for (int t = 0; t < RNG_LAG; t++) base.s[t] = window[t];
-		for (int t = 0; t < RNG_LAG - 1; t++) base.s[RNG_LAG + t] = base.s[t] + base.s[RNG_LAG - 3 + t];
 		/* v % K through floor(v / K) = (v * magic) >> (31 + l), l = ceil(log2 K), magic = ceil(2^(31+l) / K) < 2^32:
 		 * exact for every v < 2^31 (division by an invariant integer); the kernel takes the high word, so shift = l - 1 */
 		uint32_t l = 0;
@@ -1198,6 +1322,37 @@ int mchip_mstep_from_rand_partition(mchip_context *ctx, const uint32_t *window, 
 		HIPCHK(hipGetLastError());
 	}
 	return partition_mstep(ctx, ctx->d_draw, to);
+}
+
+int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, const uint32_t *window,
+			     int K, int eta_constrained, const double *q, const double *p)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	if (!window || !q || !p || K < 1) return fail(ctx, MCHIP_ERR_INVALID, "simulate_genotypes: null pointer or K < 1%s", nullptr);
+	int rc = set_shape(ctx, I, L, ploidy, ua);
+	if (rc) return rc;
+	const size_t n_copies = (size_t)I * L * ploidy;
+	rng_window base;
+	size_t n_chunks, n_blocks;
+	if ((rc = rng_stream_setup(ctx, window, 2 * n_copies, &base, &n_chunks, &n_blocks))) return rc;
+	const size_t nq = eta_constrained ? (size_t)K : (size_t)I * K, np = (size_t)K * ctx->T;
+	double *d_q = nullptr, *d_p = nullptr;
+	uint8_t *d_raw = nullptr;
+	HIPCHK(hipMalloc((void **)&d_q, nq * sizeof(double)));
+	HIPCHK(hipMalloc((void **)&d_p, np * sizeof(double)));
+	HIPCHK(hipMalloc((void **)&d_raw, n_chunks * (RNG_CHUNK / 2)));
+	HIPCHK(hipMemcpyAsync(d_q, q, nq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipMemcpyAsync(d_p, p, np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(k_simulate_admixture, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, base, ctx->d_jump_hi,
+			   ctx->d_jump_lo, n_chunks, n_copies, L, ploidy, K, ctx->T, ctx->d_toff, d_q, eta_constrained ? 0 : K, d_p,
+			   (uint32_t *)d_raw);
+	hipError_t e = hipGetLastError();
+	rc = MCHIP_OK;
+	if (e != hipSuccess) rc = fail(ctx, MCHIP_ERR_HIP, "k_simulate_admixture launch failed: %s", hipGetErrorString(e));
+	if (!rc) rc = install_raw(ctx, d_raw);
+	(void)hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d_q); (void)hipFree(d_p); (void)hipFree(d_raw);
+	return rc;
 }
 
 int mchip_get_expected_counts(mchip_context *ctx, double *sik)

@@ -61,6 +61,8 @@ def load():
         "mchip_loglik_prefetch": ([vp, i32, dp], i32),
         "mchip_mstep_from_partition": ([vp, vp, i32], i32),
         "mchip_mstep_from_rand_partition": ([vp, vp, i32], i32),
+        "mchip_get_genotypes": ([vp, vp], i32),
+        "mchip_simulate_genotypes": ([vp, i32, i32, i32, vp, vp, i32, i32, vp, vp], i32),
         "mchip_get_expected_counts": ([vp, vp], i32),
         "mchip_secant": ([vp, i32, i32, i32, i32], i32),
         "mchip_step_dots": ([vp, i32, dp], i32),
@@ -88,6 +90,7 @@ ABI_SYMBOLS = [
     "mchip_synchronize", "mchip_set_genotypes", "mchip_set_model", "mchip_set_p", "mchip_get_p", "mchip_set_q",
     "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_em_run", "mchip_last_loglik", "mchip_e_step",
     "mchip_loglik", "mchip_loglik_prefetch", "mchip_mstep_from_partition", "mchip_mstep_from_rand_partition",
+    "mchip_get_genotypes", "mchip_simulate_genotypes",
     "mchip_get_expected_counts", "mchip_secant", "mchip_step_dots",
     "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
     "mchip_profile_end", "mchip_device_info", "mchip_comm_create", "mchip_comm_all_reduce", "mchip_comm_destroy",
@@ -128,6 +131,23 @@ class Context:
         I, L, p = geno.shape
         self._chk(self.lib.mchip_set_genotypes(self.h, I, L, p, ua.ctypes.data, geno.ctypes.data))
         self.I, self.L, self.ploidy, self.T = I, L, p, int(ua.sum())
+
+    def get_genotypes(self):
+        g = np.empty((self.I, self.L, self.ploidy), dtype=np.uint8)
+        self._chk(self.lib.mchip_get_genotypes(self.h, g.ctypes.data))
+        return g
+
+    def simulate_genotypes(self, I, L, ploidy, ua, window, K, q, p, eta_constrained=0):
+        """Parametric-bootstrap data set drawn on the device (include/multiclust_hip.h); drops the model."""
+        ua = np.ascontiguousarray(ua, dtype=np.int32)
+        w = np.ascontiguousarray(window, dtype=np.uint32)
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        assert w.size == 31 and ua.size == L and p.size == K * int(ua.sum())
+        assert q.size == (K if eta_constrained else I * K)
+        self._chk(self.lib.mchip_simulate_genotypes(self.h, I, L, ploidy, ua.ctypes.data, w.ctypes.data, K,
+                                                    eta_constrained, q.ctypes.data, p.ctypes.data))
+        self.I, self.L, self.ploidy, self.T = I, L, ploidy, int(ua.sum())
 
     def set_model(self, K, admixture=1, eta_constrained=0, do_projection=1, lower_bound=1e-8, n_secants=1):
         self._chk(self.lib.mchip_set_model(self.h, K, admixture, eta_constrained, do_projection,

@@ -37,6 +37,10 @@ class McRng(C.Structure):
     _fields_ = [("r", C.c_int32 * 31), ("f", C.c_int), ("b", C.c_int)]
 
 
+class McSimulation(C.Structure):
+    _fields_ = [("window", C.c_uint32 * 31), ("K", C.c_int), ("q", C.c_void_p), ("p", C.c_void_p)]
+
+
 class McUnitResult(C.Structure):
     _fields_ = [("unit", C.c_int), ("logL", C.c_double), ("converged", C.c_int), ("n_iter", C.c_int),
                 ("time_stop", C.c_int), ("iter_stop", C.c_int), ("pindex", C.c_int), ("fatal", C.c_int),
@@ -90,6 +94,14 @@ def load():
     lib.mc_draws_per_init.restype = C.c_uint64
     lib.mc_fit_unit.argtypes = [OP, DP, MP, C.c_uint, C.c_int, C.POINTER(McUnitResult)]
     lib.mc_no_parameters.argtypes = [OP, DP, C.c_int]
+    lib.mc_bootstrap_genotypes.argtypes = [OP, DP, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(McRng), C.c_void_p]
+    lib.mc_bootstrap_genotypes.restype = None
+    lib.mc_bootstrap_draws.argtypes = [OP, DP]
+    lib.mc_bootstrap_draws.restype = C.c_uint64
+    lib.mc_simulation_begin.argtypes = [C.POINTER(McSimulation), OP, DP, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(McRng)]
+    lib.mc_simulation_begin.restype = None
+    lib.mc_model_create_simulated.argtypes = [C.POINTER(MP), OP, DP, C.c_int, C.c_int, C.POINTER(McSimulation)]
+    lib.mc_model_get_genotypes.argtypes = [MP, C.c_void_p]
     lib.mc_aic.restype = C.c_double
     lib.mc_aic.argtypes = [C.c_double, C.c_int]
     lib.mc_bic.restype = C.c_double

@@ -111,7 +111,7 @@ void mc_reset_model_state(mc_model *mod)
 	mod->seconds_run = 0;
 }
 
-int mc_model_create(mc_model **out, const mc_options *opt, const mc_data *dat, int K, int device)
+static int model_create(mc_model **out, const mc_options *opt, const mc_data *dat, int K, int device, const mc_simulation *sim)
 {
 	mc_model *mod = calloc(1, sizeof *mod);
 	int rc;
@@ -125,9 +125,13 @@ int mc_model_create(mc_model **out, const mc_options *opt, const mc_data *dat, i
 		return rc;
 	}
 	mod->owns_dev = 1;
-	if ((rc = mchip_set_genotypes(mod->dev, dat->I, dat->L, dat->ploidy, dat->uniquealleles, dat->geno)) ||
-	    (rc = mchip_set_model(mod->dev, K, opt->admixture, opt->eta_constrained, opt->do_projection,
-				  opt->eta_lower_bound, opt->p_lower_bound, opt->accel_scheme ? opt->q : 0))) {
+	if (sim)
+		rc = mchip_simulate_genotypes(mod->dev, dat->I, dat->L, dat->ploidy, dat->uniquealleles, sim->window, sim->K,
+					      opt->eta_constrained, sim->q, sim->p);
+	else
+		rc = mchip_set_genotypes(mod->dev, dat->I, dat->L, dat->ploidy, dat->uniquealleles, dat->geno);
+	if (rc || (rc = mchip_set_model(mod->dev, K, opt->admixture, opt->eta_constrained, opt->do_projection,
+					opt->eta_lower_bound, opt->p_lower_bound, opt->accel_scheme ? opt->q : 0))) {
 		fprintf(stderr, "ERROR [mc_em.c::mc_model_create]: %s\n", mchip_last_error(mod->dev));
 		mchip_destroy(mod->dev);
 		free(mod);
@@ -136,6 +140,68 @@ int mc_model_create(mc_model **out, const mc_options *opt, const mc_data *dat, i
 	mc_reset_model_state(mod);
 	*out = mod;
 	return 0;
+}
+
+int mc_model_create(mc_model **out, const mc_options *opt, const mc_data *dat, int K, int device)
+{
+	return model_create(out, opt, dat, K, device, NULL);
+}
+
+int mc_model_create_simulated(mc_model **out, const mc_options *opt, const mc_data *dat, int K, int device, const mc_simulation *sim)
+{
+	if (!sim || !opt->admixture) return MCHIP_ERR_INVALID;	/* the mixture model's replicate is drawn on the host */
+	return model_create(out, opt, dat, K, device, sim);
+}
+
+int mc_model_get_genotypes(mc_model *mod, uint8_t *geno) { return mchip_get_genotypes(mod->dev, geno); }
+
+/* ------------------------------------------------------------------ parametric bootstrap (bootstrap.c:76-175)
+ * In the default build every (i, l) receives `ploidy` simulated copies: the "missing stays missing" count copied at
+ * bootstrap.c:87 is zeroed again by the loop that follows it (m_start = 0) before n_end is taken.  Admixture: two
+ * rand() per copy (source cluster, then allele); mixture: one per individual, then one per copy. */
+static int cdf_walk(const double *w, int n, double r)
+{
+	int j = 0;
+	double sum = 0;
+	while (j < n && r > sum) sum += w[j++];
+	return j ? j - 1 : 0;
+}
+
+void mc_bootstrap_genotypes(const mc_options *opt, const mc_data *dat, int K, const double *q, const double *p,
+			    mc_rng *rng, uint8_t *geno)
+{
+	const int indiv = opt->admixture && !opt->eta_constrained;
+	int T = 0;
+	int *toff = malloc(sizeof(int) * ((size_t)dat->L + 1));
+	if (!toff) return;
+	for (int l = 0; l < dat->L; l++) { toff[l] = T; T += dat->uniquealleles[l]; }
+	toff[dat->L] = T;
+	for (int i = 0; i < dat->I; i++) {
+		int kmix = 0;
+		if (!opt->admixture) kmix = cdf_walk(q, K, (double)mc_rand(rng) / 2147483647.0);
+		for (int l = 0; l < dat->L; l++)
+			for (int n = 0; n < dat->ploidy; n++) {
+				int j = kmix;
+				if (opt->admixture) j = cdf_walk(indiv ? q + (size_t)i * K : q, K, (double)mc_rand(rng) / 2147483647.0);
+				geno[((size_t)i * dat->L + l) * dat->ploidy + n] =
+					(uint8_t)cdf_walk(p + (size_t)j * T + toff[l], dat->uniquealleles[l], (double)mc_rand(rng) / 2147483647.0);
+			}
+	}
+	free(toff);
+}
+
+uint64_t mc_bootstrap_draws(const mc_options *opt, const mc_data *dat)
+{
+	const uint64_t copies = (uint64_t)dat->I * dat->L * dat->ploidy;
+	return opt->admixture ? 2 * copies : (uint64_t)dat->I + copies;
+}
+
+void mc_simulation_begin(mc_simulation *sim, const mc_options *opt, const mc_data *dat, int K, const double *q,
+			 const double *p, mc_rng *rng)
+{
+	for (int t = 0; t < 31; t++) sim->window[t] = (uint32_t)rng->r[(rng->f + t) % 31];
+	sim->K = K; sim->q = q; sim->p = p;
+	mc_rng_jump(rng, mc_bootstrap_draws(opt, dat));
 }
 
 void mc_model_free(mc_model *mod)

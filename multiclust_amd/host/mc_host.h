@@ -86,6 +86,21 @@ int mc_synchronize(mc_options *opt, const mc_data *dat);	/* lower bounds + q, mu
 /* allocate_model_for_k (multiclust.c:1181): creates the device context on `device`, uploads dat, sizes for K */
 int mc_model_create(mc_model **mod, const mc_options *opt, const mc_data *dat, int K, int device);
 void mc_model_free(mc_model *mod);
+
+/* Parametric bootstrap (bootstrap.c:31-175).  mc_bootstrap_genotypes draws one data set on the host from the fitted
+ * parameters q ([I][K] or [K]) and p ([K][T]) of a K-cluster model, consuming `rng` exactly as the reference consumes
+ * rand(); mc_bootstrap_draws is the number of draws that takes.  For the admixture model the same data set can be
+ * generated on the device instead of uploaded: fill an mc_simulation with mc_simulation_begin (which also moves rng
+ * past the data set's draws) and create the replicate's models with mc_model_create_simulated. */
+typedef struct mc_simulation { uint32_t window[31]; int K; const double *q, *p; } mc_simulation;
+void mc_bootstrap_genotypes(const mc_options *opt, const mc_data *dat, int K, const double *q, const double *p,
+			    mc_rng *rng, uint8_t *geno);
+uint64_t mc_bootstrap_draws(const mc_options *opt, const mc_data *dat);
+void mc_simulation_begin(mc_simulation *sim, const mc_options *opt, const mc_data *dat, int K, const double *q,
+			 const double *p, mc_rng *rng);
+int mc_model_create_simulated(mc_model **mod, const mc_options *opt, const mc_data *dat, int K, int device,
+			      const mc_simulation *sim);
+int mc_model_get_genotypes(mc_model *mod, uint8_t *geno);
 const char *mc_model_error(const mc_model *mod);
 int mc_model_set_p(mc_model *mod, int slot, const double *p);
 int mc_model_get_p(mc_model *mod, int slot, double *p);

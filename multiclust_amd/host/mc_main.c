@@ -297,6 +297,7 @@ typedef struct shard_worker {
 	const mc_cli_data *d;
 	const mc_data *md;
 	int K, index, n_dev, n_units, want_params;
+	const mc_simulation *sim;	/* bootstrap replicate generated on the device, or NULL */
 	mc_rng base;			/* the serial stream's state where this K's initialisations begin */
 	uint64_t draws;
 	mc_unit_result *res;		/* [n_units], shared: worker d writes rows u = d, d + n_dev, ... */
@@ -312,7 +313,8 @@ static void *shard_main(void *arg)
 	mc_model *mod = NULL;
 	w->best_logL = -INFINITY;
 	w->best_unit = -1;
-	if ((w->rc = mc_model_create(&mod, &w->o->em, w->md, w->K, w->o->device + w->index))) return NULL;
+	if ((w->rc = w->sim ? mc_model_create_simulated(&mod, &w->o->em, w->md, w->K, w->o->device + w->index, w->sim)
+			    : mc_model_create(&mod, &w->o->em, w->md, w->K, w->o->device + w->index))) return NULL;
 	const clock_t start = clock();
 	for (int u = w->index; u < w->n_units; u += w->n_dev) {
 		mc_rng rng = w->base;
@@ -342,7 +344,8 @@ static void *shard_main(void *arg)
 }
 
 #define RES_FIELDS 9
-static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, int K, run_state *st, int bootstrap)
+static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, int K, run_state *st, int bootstrap,
+				       const mc_simulation *sim)
 {
 	const int n_dev = o->n_gpus, n_units = (K == 1) ? 1 : o->n_init;
 	const int nq = (o->em.admixture && !o->em.eta_constrained) ? d->I * K : K;
@@ -359,6 +362,7 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 	for (int x = 0; x < n_dev; x++) {
 		w[x].o = o; w[x].d = d; w[x].md = md; w[x].K = K; w[x].index = x; w[x].n_dev = n_dev; w[x].n_units = n_units;
 		w[x].want_params = keep_mle || (!bootstrap && o->write_files);
+		w[x].sim = sim;
 		w[x].base = st->rng; w[x].draws = mc_draws_per_init(&o->em, md, K); w[x].res = res;
 		devs[x] = o->device + x;
 		if (pthread_create(&th[x], NULL, shard_main, &w[x])) { rc = MCHIP_ERR_ALLOC; n_units ? (void)0 : (void)0; }
@@ -431,7 +435,9 @@ static int shardable(const mc_cli_options *o)
 }
 
 /* estimate_model (multiclust.c:365-452): K = min_K..max_K, or H0 / HA when bootstrapping */
-static int estimate_model(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, run_state *st, int bootstrap, int *total_iter)
+/* sim != NULL: the models are fitted to the bootstrap data set it describes, generated on each device (admixture) */
+static int estimate_model(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, run_state *st, int bootstrap, int *total_iter,
+			  const mc_simulation *sim)
 {
 	int K = o->n_bootstrap ? st->null_K : o->min_K, rc = 0;
 	double min_aic = INFINITY, min_bic = INFINITY;
@@ -441,10 +447,11 @@ static int estimate_model(const mc_cli_options *o, const mc_cli_data *d, const m
 	if (total_iter) *total_iter = 0;
 	for (;;) {
 		if (shardable(o)) {
-			rc = maximize_likelihood_sharded(o, d, md, K, st, bootstrap);
+			rc = maximize_likelihood_sharded(o, d, md, K, st, bootstrap, sim);
 		} else {
 			mc_model *mod = NULL;
-			if ((rc = mc_model_create(&mod, &o->em, md, K, o->device))) return rc;
+			if ((rc = sim ? mc_model_create_simulated(&mod, &o->em, md, K, o->device, sim)
+				      : mc_model_create(&mod, &o->em, md, K, o->device))) return rc;
 			rc = maximize_likelihood(o, d, md, mod, st, bootstrap);
 			mc_model_free(mod);
 		}
@@ -469,39 +476,6 @@ static int estimate_model(const mc_cli_options *o, const mc_cli_data *d, const m
 		if (!bootstrap) st->ts_obs = diff; else st->ts_bs = diff;
 	}
 	return 0;
-}
-
-/* parametric_bootstrap_{admixture,mixture} (bootstrap.c:76-175) in default mode: every (i,l) receives `ploidy`
- * simulated copies (two rand() per copy for admixture: source cluster, then allele); written as genotype bytes */
-static void bootstrap_genotypes(const mc_cli_options *o, const mc_cli_data *d, run_state *st, uint8_t *geno)
-{
-	const int K = st->mle_K, T = d->T;
-	const int indiv = o->em.admixture && !o->em.eta_constrained;
-	for (int i = 0; i < d->I; i++) {
-		int kmix = 0;
-		if (!o->em.admixture) {
-			double r = (double)mc_rand(&st->rng) / 2147483647.0, sum = 0;
-			while (kmix < K && r > sum) sum += st->mle_q[kmix++];
-			if (kmix) kmix--;
-		}
-		for (int l = 0; l < d->L; l++)
-			for (int n = 0; n < d->ploidy; n++) {
-				int j = kmix;
-				double r, sum;
-				if (o->em.admixture) {
-					r = (double)mc_rand(&st->rng) / 2147483647.0;
-					j = 0; sum = 0;
-					while (j < K && r > sum) sum += indiv ? st->mle_q[(size_t)i * K + j++] : st->mle_q[j++];
-					if (j) j--;
-				}
-				r = (double)mc_rand(&st->rng) / 2147483647.0;
-				int m = 0;
-				sum = 0;
-				while (m < d->uniquealleles[l] && r > sum) sum += st->mle_p[(size_t)j * T + d->toff[l] + m++];
-				if (m) m--;
-				geno[((size_t)i * d->L + l) * d->ploidy + n] = (uint8_t)m;
-			}
-	}
 }
 
 int main(int argc, const char **argv)
@@ -536,7 +510,7 @@ int main(int argc, const char **argv)
 		int n = 0, conv = 0, enough = o.repeat_seconds ? 0 : 1, total;
 		char ab[16];
 		while (n < o.n_repeat || !enough) {
-			if ((rc = estimate_model(&o, &d, &md, &st, 0, &total))) goto END;
+			if ((rc = estimate_model(&o, &d, &md, &st, 0, &total, NULL))) goto END;
 			if (st.sum.max_logL > max_ll) max_ll = st.sum.max_logL;
 			sum_ll += st.sum.max_logL; sum_ll2 += st.sum.max_logL * st.sum.max_logL;
 			sum_init += st.sum.n_init; sum_iter += st.sum.n_total_iter;
@@ -557,21 +531,30 @@ int main(int argc, const char **argv)
 		printf("Average log likelihood: %f (+/- %f)\n", sum_ll / n, sqrt((sum_ll2 - sum_ll * sum_ll / n) / (n - 1)));
 		printf("Maximum log likelihood: %f\n", max_ll);
 		printf("Total initializations, iterations: %d, %d\n", (int)sum_init, (int)sum_iter);
-	} else if ((rc = estimate_model(&o, &d, &md, &st, 0, NULL))) {
+	} else if ((rc = estimate_model(&o, &d, &md, &st, 0, NULL, NULL))) {
 		goto END;
 	}
 	if (o.parallel) printf("%f\n", st.sum.max_logL);	/* multiclust.c:143-145 */
 
 	if (o.n_bootstrap) {	/* run_bootstrap (multiclust.c:675-708) */
-		uint8_t *orig = d.geno, *sim = malloc((size_t)d.I * d.L * d.ploidy);
+		/* admixture: the replicate is generated on the device(s) from the stream position (no host data set, no upload);
+		 * mixture (or MC_HOST_BOOTSTRAP): drawn on the host and uploaded like any data set */
+		const int on_device = o.em.admixture && !getenv("MC_HOST_BOOTSTRAP");
+		uint8_t *orig = d.geno, *sim = on_device ? NULL : malloc((size_t)d.I * d.L * d.ploidy);
 		int ntime = 0;
-		if (!sim || !st.mle_q) { rc = MCHIP_ERR_ALLOC; goto END; }
+		if ((!on_device && !sim) || !st.mle_q) { rc = MCHIP_ERR_ALLOC; goto END; }
 		for (int b = 0; b < o.n_bootstrap; b++) {
 			printf("Bootstrap dataset %d (of %d):", b + 1, o.n_bootstrap);
-			bootstrap_genotypes(&o, &d, &st, sim);
-			md.geno = d.geno = sim;
-			rc = estimate_model(&o, &d, &md, &st, 1, NULL);
-			md.geno = d.geno = orig;
+			if (on_device) {
+				mc_simulation gen;
+				mc_simulation_begin(&gen, &o.em, &md, st.mle_K, st.mle_q, st.mle_p, &st.rng);
+				rc = estimate_model(&o, &d, &md, &st, 1, NULL, &gen);
+			} else {
+				mc_bootstrap_genotypes(&o.em, &md, st.mle_K, st.mle_q, st.mle_p, &st.rng, sim);
+				md.geno = d.geno = sim;
+				rc = estimate_model(&o, &d, &md, &st, 1, NULL, NULL);
+				md.geno = d.geno = orig;
+			}
 			if (rc) { free(sim); goto END; }
 			if (st.ts_bs >= st.ts_obs) ntime++;
 			printf(" test statistics bs=%f obs=%f (%f)\n", st.ts_bs, st.ts_obs, (double)ntime / (b + 1));

@@ -63,13 +63,19 @@ def write_c1(path):
                 f.write("ind%d pop%d " % (i, pop) + " ".join(row) + "\n")
 
 
+BOOTSTRAP_CASES = ("multi_admix_k4", "tetra_admix_k3", "missing_admix_k3", "multi_mix_k3", "multi_admix_c_k3")
+
+
 def run(name, stru, n_em, snaps, n_cycles, args, keep_ilm=True):
     out = os.path.join(GOLD, name)
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)
     cmd = [HARNESS, out, str(n_em), snaps, str(n_cycles), "--", "-f", stru] + args
     print(" ".join(cmd))
-    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, cwd=out)
+    env = dict(os.environ)
+    if name in BOOTSTRAP_CASES:     # section 6 of the harness: one parametric-bootstrap data set (bs_ilm.u8)
+        env["REF_HARNESS_BOOTSTRAP"] = "1"
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, cwd=out, env=env)
     with open(os.path.join(out, "ARGS.txt"), "w") as f:
         f.write(" ".join(["-f", os.path.basename(stru)] + args) + "\n")
     if not keep_ilm:

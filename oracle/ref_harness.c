@@ -435,6 +435,38 @@ int main(int argc, const char **argv)
 		man_dbl("mi_aic", mod->aic); man_dbl("mi_bic", mod->bic);
 	}
 
+	/* ---- section 6: parametric_bootstrap (bootstrap.c:31-175) known answers: one simulated data set drawn from the
+	 * parameters reached after three EM steps (standing in for the H0 MLEs), rand() stream seeded with seed + 7 ---- */
+	if (getenv("REF_HARNESS_BOOTSTRAP")) {
+		opt->accel_scheme = 0;
+		opt->q = 1;
+		reset_model_state(opt, mod);
+		if ((err = initialize_model(opt, dat, mod))) die("initialize_model failed");
+		for (int s = 0; s < 3; s++) em_step(opt, dat, mod);
+		dump_q("q_bs.f64", opt, dat, mod, 0);
+		dump_p("p_bs.f64", dat, mod, 0);
+		mod->mle_pKLM = malloc(mod->K * sizeof *mod->mle_pKLM);
+		for (int k = 0; k < mod->K; k++) mod->mle_pKLM[k] = mod->vpklm[0][k];	/* read-only aliases */
+		if (opt->admixture && !opt->eta_constrained) mod->mle_etaik = mod->vetaik[0];
+		else mod->mle_etak = mod->vetak[0];
+		srand(opt->seed + 7);
+		if ((err = parametric_bootstrap(opt, dat, mod))) die("parametric_bootstrap failed");
+		man_key("rand_after_bootstrap"); fprintf(man, "%d", rand());
+		f = xopen("bs_ilm.u8");
+		for (int i = 0; i < dat->I; i++)
+			for (int l = 0; l < dat->L; l++)
+				for (int m = 0; m < dat->uniquealleles[l]; m++) {
+					uint8_t c = (uint8_t)dat->ILM[i][l][m];
+					if (dat->ILM[i][l][m] < 0 || dat->ILM[i][l][m] > 255) die("bootstrap count out of range");
+					fwrite(&c, 1, 1, f);
+				}
+		fclose(f);
+		cleanup_parametric_bootstrap(dat);
+		free(mod->mle_pKLM);
+		mod->mle_pKLM = NULL; mod->mle_etaik = NULL; mod->mle_etak = NULL;
+		man_int("bootstrap_seed", (long)opt->seed + 7);
+	}
+
 	fprintf(man, "\n}\n");
 	fclose(man);
 	return 0;

@@ -100,12 +100,22 @@ def test_cli_k_range_and_quiet_mode(tmp_path):
     assert abs(float(out[1]) - float(out[0].split()[9])) < 1e-6
 
 
-def test_cli_bootstrap_runs(tmp_path):
+def test_cli_bootstrap_device_and_host_generators_agree(tmp_path, monkeypatch):
+    """-b: the reference's own binary aborts in its second model ("free(): invalid pointer"), so there is no golden
+    stdout; the replicate generator itself is pinned to the reference's parametric_bootstrap() in
+    tests/test_bootstrap_cpu.py / test_gpu_bootstrap.py.  Here: the run completes, and generating the replicates on
+    the device gives the same test statistics as drawing them on the host and uploading them."""
     stru = os.path.join(GOLD, "data", "multi.stru")
-    res = subprocess.run([BIN, "-f", stru, "-a", "-k", "2", "-n", "2", "-b", "2", "-r", "9", "-s", "3", "-d", str(tmp_path)],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr
-    assert res.stdout.count("Bootstrap dataset") == 2 and "p-value to reject H0: K=1" in res.stdout
+    cmd = [BIN, "-f", stru, "-a", "-k", "2", "-n", "2", "-b", "3", "-r", "9", "-s", "3", "-d", str(tmp_path)]
+    outs = []
+    for host_side in (False, True):
+        if host_side:
+            monkeypatch.setenv("MC_HOST_BOOTSTRAP", "1")
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr
+        assert res.stdout.count("Bootstrap dataset") == 3 and "p-value to reject H0: K=1" in res.stdout
+        outs.append([l for l in CLOCK.sub("HH:MM:SS", res.stdout).split("\n") if "Bootstrap dataset" in l or "p-value" in l])
+    assert outs[0] == outs[1], outs
 
 
 @pytest.mark.parametrize("case", ["multi_admix_k4", "tetra_admix_k3"])
