@@ -52,3 +52,38 @@ for rep in range(2):
     t2 = time.perf_counter()
     print("host draw %.1f ms (%d threads) + upload and first M step %.1f ms" % ((t1 - t0) * 1e3, min(16, os.cpu_count()), (t2 - t1) * 1e3), flush=True)
 print("identical:", bool(np.array_equal(p_dev, ctx.get_p(1))))
+
+# ---- parametric-bootstrap replicate: generated on the device against drawn on the host (serial, as in the reference)
+if os.environ.get("INITBENCH_BOOTSTRAP", "1") != "0":
+    Kb = a.K
+    T = int(ua.sum())
+    q = rs.dirichlet(np.full(Kb, 0.3), a.I)
+    p = np.empty((Kb, T))
+    toff = np.concatenate([[0], np.cumsum(ua)])
+    for M in (2, 3, 4):
+        cols = toff[:-1][ua == M]
+        d = rs.dirichlet(np.full(M, 0.5), (Kb, cols.size))
+        for m in range(M):
+            p[:, cols + m] = d[:, :, m]
+    for rep in range(3):
+        t0 = time.perf_counter()
+        ctx.simulate_genotypes(a.I, a.L, a.ploidy, ua, window, Kb, q, p)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        print("device bootstrap data set (generate + layouts + counts): %.1f ms" % ((t1 - t0) * 1e3), flush=True)
+    sub = max(1, a.I // 50)
+    opt = host.McOptions()
+    hl.mc_make_options(C.byref(opt))
+    opt.admixture = 1
+    ua32 = np.ascontiguousarray(ua, dtype=np.int32)
+    gsub = np.ascontiguousarray(geno[:sub])
+    dat = host.McData(sub, a.L, a.ploidy, ua32.ctypes.data, gsub.ctypes.data)
+    out = np.empty_like(gsub)
+    qs = np.ascontiguousarray(q[:sub])
+    hl.mc_srand(C.byref(rng), 1234567)
+    t0 = time.perf_counter()
+    hl.mc_bootstrap_genotypes(C.byref(opt), C.byref(dat), Kb, qs.ctypes.data, p.ctypes.data, C.byref(rng), out.ctypes.data)
+    t1 = time.perf_counter()
+    print("host bootstrap data set: %.2f s for %d of %d individuals -> %.1f s for all (one core), + upload" %
+          (t1 - t0, sub, a.I, (t1 - t0) * a.I / sub), flush=True)
+    print("first individuals identical:", bool(np.array_equal(ctx.get_genotypes()[:sub], out)))
