@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--accel", type=int, default=None, help="override the workload's acceleration scheme (0..6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra config-2 line (profiling runs: its kernels "
+                    "carry the same names as the headline workload's)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -272,7 +274,7 @@ def main():
         # HBM traffic per launch of the dominant kernel: PMC FETCH_SIZE/WRITE_SIZE from separate `rocprofv3 --pmc` passes
         # of this same command (scripts/summarize_profile.py; corrected as MI355X_MICROARCH.md prescribes), config 3 only
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_v2_c3_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r01_v3_c3_traffic.json")
         if args.workload == "c3" and os.path.exists(tf):
             want = "k_column_counts<2, false>" if dom == 0 else "k_individual_sparse<2, true, false, true>"
             traffic = json.load(open(tf)).get(want, {}).get("hbm_bytes_per_launch_corrected")
@@ -303,7 +305,7 @@ def main():
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     fit.close()
     if rank == 0:
-        if world == 1 and args.workload == "c3":
+        if world == 1 and args.workload == "c3" and not args.no_secondary:
             out["secondary"] = secondary_run("c2", dev, local_rank)
         print(json.dumps(out), flush=True)
     if dist is not None:
