@@ -194,6 +194,7 @@ typedef struct run_state {
 	double *mle_q, *mle_p;		/* H0 MLEs for the bootstrap (multiclust.c:562-581) */
 	int mle_K;
 	mc_rng rng;
+	FILE *out;			/* stdout, or a replicate's buffer when bootstrap replicates run on several devices */
 } run_state;
 
 static void print_model_state(const mc_cli_options *o, const mc_cli_data *d, const run_state *st, int K, int diff, int newline)
@@ -201,22 +202,22 @@ static void print_model_state(const mc_cli_options *o, const mc_cli_data *d, con
 	char ab[16];
 	(void)d;
 	if (o->compact) {	/* multiclust.c:720-746 */
-		printf("%s %s %s %d %u %e %e %e %e %f %f %f ", o->filename, accel_abbrev(o, ab), o->em.admixture ? "admix" : "mix", K,
+		fprintf(st->out, "%s %s %s %d %u %e %e %e %e %f %f %f ", o->filename, accel_abbrev(o, ab), o->em.admixture ? "admix" : "mix", K,
 		       o->em.seed, o->em.eta_lower_bound, o->em.p_lower_bound, o->em.abs_error, o->em.rel_error,
 		       st->sum.max_logL, st->sum.aic, st->sum.bic);
-		printf("ND ");
-		printf("%s %02d:%02d:%02d %d %d %d %d", st->sum.ever_converged ? "converged" : "not", diff / 3600, (diff % 3600) / 60,
+		fprintf(st->out, "ND ");
+		fprintf(st->out, "%s %02d:%02d:%02d %d %d %d %d", st->sum.ever_converged ? "converged" : "not", diff / 3600, (diff % 3600) / 60,
 		       diff % 60, st->sum.n_total_iter, st->sum.n_init, st->sum.n_maxll_init, st->sum.n_maxll_times);
-		if (o->target_ll) printf(" %f %d %d", o->desired_ll, st->n_targetll_init, st->n_targetll_times);
-		if (st->time_stop) printf(" time");
-		if (newline) printf("\n");
+		if (o->target_ll) fprintf(st->out, " %f %d %d", o->desired_ll, st->n_targetll_init, st->n_targetll_times);
+		if (st->time_stop) fprintf(st->out, " time");
+		if (newline) fprintf(st->out, "\n");
 	} else {		/* multiclust.c:748-792 */
-		printf("Dataset: %s\nMethod/Model: %s, %s, K=%d\n", o->filename, accel_abbrev(o, ab), o->em.admixture ? "admix" : "mix", K);
-		printf("Convergence: ae=%e, re=%e\nBounds: e=%e, p=%e\n", o->em.abs_error, o->em.rel_error, o->em.eta_lower_bound, o->em.p_lower_bound);
-		printf("Total number of iterations: %d\nTotal time: %02d:%02d:%02d\n", st->sum.n_total_iter, diff / 3600, (diff % 3600) / 60, diff % 60);
-		printf("Iteration of max log likelihood: %d of %d\nNumber of times reach max log likelihood: %d\n", st->sum.n_maxll_init, st->sum.n_init, st->sum.n_maxll_times);
-		printf("Maximum log likelihood: %f\nAIC: %f\nBIC: %f\nConverged: %s\n", st->sum.max_logL, st->sum.aic, st->sum.bic, st->sum.ever_converged ? "yes" : "no");
-		if (st->time_stop) printf("WARNING: Fitting stopped because ran out of time\n");
+		fprintf(st->out, "Dataset: %s\nMethod/Model: %s, %s, K=%d\n", o->filename, accel_abbrev(o, ab), o->em.admixture ? "admix" : "mix", K);
+		fprintf(st->out, "Convergence: ae=%e, re=%e\nBounds: e=%e, p=%e\n", o->em.abs_error, o->em.rel_error, o->em.eta_lower_bound, o->em.p_lower_bound);
+		fprintf(st->out, "Total number of iterations: %d\nTotal time: %02d:%02d:%02d\n", st->sum.n_total_iter, diff / 3600, (diff % 3600) / 60, diff % 60);
+		fprintf(st->out, "Iteration of max log likelihood: %d of %d\nNumber of times reach max log likelihood: %d\n", st->sum.n_maxll_init, st->sum.n_init, st->sum.n_maxll_times);
+		fprintf(st->out, "Maximum log likelihood: %f\nAIC: %f\nBIC: %f\nConverged: %s\n", st->sum.max_logL, st->sum.aic, st->sum.bic, st->sum.ever_converged ? "yes" : "no");
+		if (st->time_stop) fprintf(st->out, "WARNING: Fitting stopped because ran out of time\n");
 	}
 }
 
@@ -269,7 +270,7 @@ static int maximize_likelihood(const mc_cli_options *o, const mc_cli_data *d, co
 			}
 		}
 		if (!bootstrap && o->em.verbosity > MC_QUIET && o->write_files)	/* multiclust.c:618-627 */
-			printf("K = %d, initialization = %d: %f (%s) in %3d iterations, %02d:%02d:%02d (%f; %d), seed: %u\n", K, i, mod->logL,
+			fprintf(st->out, "K = %d, initialization = %d: %f (%s) in %3d iterations, %02d:%02d:%02d (%f; %d), seed: %u\n", K, i, mod->logL,
 			       mod->converged ? "converged" : "not converged", mod->n_iter, (int)(mod->seconds_run / 3600),
 			       (int)((((int)mod->seconds_run) % 3600) / 60), ((int)mod->seconds_run) % 60, st->sum.max_logL,
 			       st->sum.n_maxll_times, o->em.seed);
@@ -397,7 +398,7 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 		mc_unit_result r = { u, row[0], (int)row[1], (int)row[2], (int)row[3], (int)row[4], (int)row[5], 0, row[7] };
 		mc_summary_add(&o->em, &st->sum, &r, npar, d->I);
 		if (!bootstrap && o->em.verbosity > MC_QUIET && o->write_files)
-			printf("K = %d, initialization = %d: %f (%s) in %3d iterations, %02d:%02d:%02d (%f; %d), seed: %u\n", K, u, r.logL,
+			fprintf(st->out, "K = %d, initialization = %d: %f (%s) in %3d iterations, %02d:%02d:%02d (%f; %d), seed: %u\n", K, u, r.logL,
 			       r.converged ? "converged" : "not converged", r.n_iter, (int)(r.seconds_run / 3600),
 			       (int)((((int)r.seconds_run) % 3600) / 60), ((int)r.seconds_run) % 60, st->sum.max_logL, st->sum.n_maxll_times, o->em.seed);
 	}
@@ -431,7 +432,7 @@ static int shardable(const mc_cli_options *o)
 	/* MC_FORCE_SHARDED=1 sends even --gpus 1 through the sharded path (threads, jump-ahead, RCCL exchange, replay): the
 	 * single-GPU rehearsal used by tests/test_gpu_cli.py */
 	const int force = getenv("MC_FORCE_SHARDED") != NULL;
-	return (o->n_gpus > 1 || force) && o->em.admixture && !o->target_revisit && !o->target_ll && !o->em.n_seconds;
+	return (o->n_gpus > 1 || (force && o->n_gpus == 1)) && o->em.admixture && !o->target_revisit && !o->target_ll && !o->em.n_seconds;
 }
 
 /* estimate_model (multiclust.c:365-452): K = min_K..max_K, or H0 / HA when bootstrapping */
@@ -478,6 +479,92 @@ static int estimate_model(const mc_cli_options *o, const mc_cli_data *d, const m
 	return 0;
 }
 
+/* ---- bootstrap replicates sharded over the GPUs of the node as whole units ----
+ * Replicate b = data set + H0 fits + HA fits consumes a data-independent number of rand() draws, so device x takes
+ * replicates x, x + n_dev, ... each from the stream jumped to where the serial program would be, generates the data
+ * set on its own GPU and fits both models there; its stdout goes to a buffer.  One RCCL all-reduce completes the table
+ * of test statistics on every device; the buffers are then printed in replicate order with the running p-value. */
+typedef struct bs_worker {
+	const mc_cli_options *o;
+	const mc_cli_data *d;
+	const mc_data *md;
+	const run_state *st;		/* observed-data results: null_K, alt_K, H0 MLEs, ts_obs */
+	int index, n_dev;
+	uint64_t draws_per_replicate;
+	double *ts;			/* [n_bootstrap], shared: worker x writes entries b = x, x + n_dev, ... */
+	char **text;			/* [n_bootstrap] captured stdout of each replicate */
+	int rc;
+} bs_worker;
+
+static void *bs_main(void *arg)
+{
+	bs_worker *w = arg;
+	mc_cli_options ow = *w->o;
+	ow.device = w->o->device + w->index;
+	ow.n_gpus = 0;			/* the fits of a replicate stay on this device */
+	for (int b = w->index; b < w->o->n_bootstrap; b += w->n_dev) {
+		run_state ls = *w->st;
+		mc_simulation gen;
+		size_t len = 0;
+		ls.mle_q = w->st->mle_q; ls.mle_p = w->st->mle_p;	/* read only */
+		mc_rng_jump(&ls.rng, (uint64_t)b * w->draws_per_replicate);
+		if (!(ls.out = open_memstream(&w->text[b], &len))) { w->rc = MCHIP_ERR_ALLOC; return NULL; }
+		fprintf(ls.out, "Bootstrap dataset %d (of %d):", b + 1, w->o->n_bootstrap);
+		mc_simulation_begin(&gen, &ow.em, w->md, ls.mle_K, ls.mle_q, ls.mle_p, &ls.rng);
+		w->rc = estimate_model(&ow, w->d, w->md, &ls, 1, NULL, &gen);
+		fclose(ls.out);
+		if (w->rc) return NULL;
+		w->ts[b] = ls.ts_bs;
+	}
+	return NULL;
+}
+
+static int run_bootstrap_sharded(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, run_state *st, int *ntime_out)
+{
+	const int n_dev = o->n_gpus < 1 ? 1 : o->n_gpus, B = o->n_bootstrap;
+	const uint64_t per_init = mc_draws_per_init(&o->em, md, st->alt_K);
+	const uint64_t units0 = st->null_K == 1 ? 1 : (uint64_t)o->n_init, units1 = (uint64_t)o->n_init;
+	bs_worker *w = calloc((size_t)n_dev, sizeof *w);
+	pthread_t *th = calloc((size_t)n_dev, sizeof *th);
+	double *ts = calloc((size_t)B, sizeof *ts), **tab = calloc((size_t)n_dev, sizeof *tab);
+	char **text = calloc((size_t)B, sizeof *text);
+	int *devs = calloc((size_t)n_dev, sizeof *devs), rc = 0, ntime = 0;
+	mchip_comm *comm = NULL;
+	if (!w || !th || !ts || !tab || !text || !devs) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+	for (int x = 0; x < n_dev; x++) {
+		w[x].o = o; w[x].d = d; w[x].md = md; w[x].st = st; w[x].index = x; w[x].n_dev = n_dev;
+		w[x].draws_per_replicate = mc_bootstrap_draws(&o->em, md) + (units0 + units1) * per_init;
+		w[x].ts = ts; w[x].text = text;
+		devs[x] = o->device + x;
+		if (pthread_create(&th[x], NULL, bs_main, &w[x])) { bs_main(&w[x]); th[x] = 0; }
+	}
+	for (int x = 0; x < n_dev; x++) if (th[x]) pthread_join(th[x], NULL);
+	for (int x = 0; x < n_dev; x++) if (w[x].rc) rc = w[x].rc;
+	if (rc) goto DONE;
+	mc_rng_jump(&st->rng, (uint64_t)B * w[0].draws_per_replicate);
+	/* the one exchange: rows (test statistic, fitted flag) of the replicates each device owns, summed over devices */
+	for (int x = 0; x < n_dev; x++) {
+		if (!(tab[x] = calloc((size_t)B * 2, sizeof(double)))) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+		for (int b = x; b < B; b += n_dev) { tab[x][2 * b] = ts[b]; tab[x][2 * b + 1] = 1.0; }
+	}
+	if ((rc = mchip_comm_create(&comm, n_dev, devs))) { fprintf(stderr, "ERROR [mc_main.c]: cannot create the RCCL communicator (status %d)\n", rc); goto DONE; }
+	if ((rc = mchip_comm_all_reduce(comm, tab, B * 2, 0))) { fprintf(stderr, "ERROR [mc_main.c]: %s\n", mchip_comm_last_error(comm)); goto DONE; }
+	for (int b = 0; b < B; b++) {
+		if (tab[0][2 * b + 1] != 1.0) { fprintf(stderr, "ERROR [mc_main.c]: bootstrap replicate %d was fitted %g times\n", b, tab[0][2 * b + 1]); rc = MCHIP_ERR_STATE; goto DONE; }
+		st->ts_bs = tab[0][2 * b];
+		if (st->ts_bs >= st->ts_obs) ntime++;
+		fputs(text[b] ? text[b] : "", stdout);
+		printf(" test statistics bs=%f obs=%f (%f)\n", st->ts_bs, st->ts_obs, (double)ntime / (b + 1));
+	}
+	*ntime_out = ntime;
+DONE:
+	if (comm) mchip_comm_destroy(comm);
+	if (tab) for (int x = 0; x < n_dev; x++) free(tab[x]);
+	if (text) for (int b = 0; b < B; b++) free(text[b]);
+	free(w); free(th); free(ts); free(tab); free(text); free(devs);
+	return rc;
+}
+
 int main(int argc, const char **argv)
 {
 	mc_cli_options o;
@@ -497,6 +584,7 @@ int main(int argc, const char **argv)
 	if (o.min_K > o.max_K) { fprintf(stderr, "ERROR: Minimum K (%d) must not exceed maximum K (%d).\n", o.min_K, o.max_K); return 2; }
 	if (!o.target_ll && !o.target_revisit && !o.em.n_seconds && !o.n_init) o.n_init = 1;
 	memset(&st, 0, sizeof st);
+	st.out = stdout;
 	if (o.n_bootstrap) { st.null_K = o.max_K - 1; st.alt_K = o.max_K; }
 	/* the reference seeds libc only when -r is given; otherwise rand() runs from glibc's default seed 1 although the
 	 * banner prints 1234567 */
@@ -543,7 +631,11 @@ int main(int argc, const char **argv)
 		uint8_t *orig = d.geno, *sim = on_device ? NULL : malloc((size_t)d.I * d.L * d.ploidy);
 		int ntime = 0;
 		if ((!on_device && !sim) || !st.mle_q) { rc = MCHIP_ERR_ALLOC; goto END; }
-		for (int b = 0; b < o.n_bootstrap; b++) {
+		/* whole replicates per device when there is at least one for each; otherwise (or on one device) the replicates run in
+		 * turn and --gpus shards the initialisations inside each */
+		const int by_replicate = on_device && shardable(&o) && o.n_bootstrap >= o.n_gpus;
+		if (by_replicate && (rc = run_bootstrap_sharded(&o, &d, &md, &st, &ntime))) goto END;
+		for (int b = 0; !by_replicate && b < o.n_bootstrap; b++) {
 			printf("Bootstrap dataset %d (of %d):", b + 1, o.n_bootstrap);
 			if (on_device) {
 				mc_simulation gen;

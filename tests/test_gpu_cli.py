@@ -100,22 +100,32 @@ def test_cli_k_range_and_quiet_mode(tmp_path):
     assert abs(float(out[1]) - float(out[0].split()[9])) < 1e-6
 
 
-def test_cli_bootstrap_device_and_host_generators_agree(tmp_path, monkeypatch):
+def test_cli_bootstrap_device_host_and_sharded_agree(tmp_path, monkeypatch):
     """-b: the reference's own binary aborts in its second model ("free(): invalid pointer"), so there is no golden
     stdout; the replicate generator itself is pinned to the reference's parametric_bootstrap() in
-    tests/test_bootstrap_cpu.py / test_gpu_bootstrap.py.  Here: the run completes, and generating the replicates on
-    the device gives the same test statistics as drawing them on the host and uploading them."""
+    tests/test_bootstrap_cpu.py / test_gpu_bootstrap.py.  Here: the run completes, and three ways of running it print
+    the same thing: replicates generated on the device, replicates drawn on the host and uploaded, and whole replicates
+    sharded over devices (rehearsed with one device: worker thread, rand() jump-ahead per replicate, captured stdout,
+    RCCL all-reduce of the test statistics, in-order replay)."""
     stru = os.path.join(GOLD, "data", "multi.stru")
-    cmd = [BIN, "-f", stru, "-a", "-k", "2", "-n", "2", "-b", "3", "-r", "9", "-s", "3", "-d", str(tmp_path)]
+    cmd = [BIN, "-f", stru, "-a", "-k", "3", "-n", "2", "-b", "3", "-r", "9", "-s", "3", "-d", str(tmp_path)]
     outs = []
-    for host_side in (False, True):
-        if host_side:
+    for mode in ("device", "host", "sharded"):
+        monkeypatch.delenv("MC_HOST_BOOTSTRAP", raising=False)
+        monkeypatch.delenv("MC_FORCE_SHARDED", raising=False)
+        extra = []
+        if mode == "host":
             monkeypatch.setenv("MC_HOST_BOOTSTRAP", "1")
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        if mode == "sharded":
+            monkeypatch.setenv("MC_FORCE_SHARDED", "1")
+            extra = ["--gpus", "1"]
+        res = subprocess.run(cmd + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert res.returncode == 0, res.stderr
-        assert res.stdout.count("Bootstrap dataset") == 3 and "p-value to reject H0: K=1" in res.stdout
-        outs.append([l for l in CLOCK.sub("HH:MM:SS", res.stdout).split("\n") if "Bootstrap dataset" in l or "p-value" in l])
+        assert res.stdout.count("Bootstrap dataset") == 3 and "p-value to reject H0: K=2" in res.stdout
+        text = CLOCK.sub("HH:MM:SS", res.stdout)
+        outs.append(text[text.index("Bootstrap dataset 1"):])
     assert outs[0] == outs[1], outs
+    assert outs[0] == outs[2], outs
 
 
 @pytest.mark.parametrize("case", ["multi_admix_k4", "tetra_admix_k3"])
