@@ -72,6 +72,14 @@ int mchip_get_genotypes(mchip_context *ctx, uint8_t *geno);
  */
 int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int32_t *uniquealleles,
 			     const uint32_t *window, int K, int eta_constrained, const double *q, const double *p);
+/*
+ * The genotype the hard-partition M step reads, when it is not the data set itself.  While bootstrapping, the
+ * reference's random_allele_partition still reads the observed haplotypes dat->IL (rnd_init.c:471;
+ * parametric_bootstrap replaces only dat->ILM, bootstrap.c:35-41), so every fit to a simulated data set starts from
+ * the observed alleles.  After this call mchip_mstep_from_partition / _from_rand_partition on this context do the
+ * same; geno = NULL (and any new data set) goes back to the data set itself.  Same form as mchip_set_genotypes.
+ */
+int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno);
 
 /*
  * Allocate parameter ring, secant buffers and workspaces for K.  Replaces allocate_model_for_k

@@ -46,6 +46,7 @@ struct mchip_context {
 	int count_bits, has_missing;
 	size_t geno_bytes_A, geno_bytes_S;
 	uint8_t *d_asA, *d_asS;		/* hard-partition scratch, allocated on first use */
+	uint8_t *d_initA, *d_initS;	/* genotype the hard-partition M step reads when it is not the data set itself (bootstrap) */
 	uint8_t *d_draw;		/* device-drawn partition in stream order [I][L][ploidy], padded to whole chunks */
 	uint32_t *d_jump_hi, *d_jump_lo;	/* jump polynomials of the rand() stream (mchip_mstep_from_rand_partition) */
 	size_t n_jump_hi;
@@ -599,6 +600,7 @@ static void free_data(mchip_context *ctx)
 {
 	dfree(ctx->d_ua); dfree(ctx->d_toff); dfree(ctx->d_col_locus); dfree(ctx->d_col_allele);
 	dfree(ctx->d_gtA); dfree(ctx->d_gtS); dfree(ctx->d_gtC); dfree(ctx->d_asA); dfree(ctx->d_asS);
+	dfree(ctx->d_initA); dfree(ctx->d_initS);
 	dfree(ctx->d_draw); dfree(ctx->d_jump_hi); dfree(ctx->d_jump_lo);
 	ctx->n_jump_hi = 0;
 	ctx->I = ctx->L = ctx->T = 0;
@@ -797,6 +799,41 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	rc = install_raw(ctx, d_raw);
 	(void)hipFree(d_raw);
 	return rc;
+}
+
+int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "no genotypes set%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	dfree(ctx->d_initA);
+	dfree(ctx->d_initS);
+	if (!geno) return MCHIP_OK;
+	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
+	uint8_t *d_obs = nullptr;
+	int *d_bad = nullptr;
+	HIPCHK(hipMalloc((void **)&d_obs, n));
+	HIPCHK(hipMalloc((void **)&d_bad, sizeof(int)));
+	HIPCHK(hipMalloc((void **)&ctx->d_initA, ctx->geno_bytes_A));
+	HIPCHK(hipMalloc((void **)&ctx->d_initS, ctx->geno_bytes_S));
+	HIPCHK(hipMemcpyAsync(d_obs, geno, n, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
+	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_obs, ctx->I, ctx->L, ctx->ploidy, ctx->d_ua, 0,
+			   ctx->d_initA, ctx->d_initS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
+	HIPCHK(hipGetLastError());
+	int bad = 0;
+	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	(void)hipFree(d_obs);
+	(void)hipFree(d_bad);
+	if (bad & 1) {
+		dfree(ctx->d_initA);
+		dfree(ctx->d_initS);
+		return fail(ctx, MCHIP_ERR_INVALID, "init genotype allele index >= uniquealleles[l]%s", nullptr);
+	}
+	return MCHIP_OK;
 }
 
 int mchip_get_genotypes(mchip_context *ctx, uint8_t *geno)
@@ -1202,6 +1239,10 @@ static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to)
 	if (bad) return fail(ctx, MCHIP_ERR_INVALID, "partition assignment >= K%s", nullptr);
 
 	mchip_pass_args a = pass_args(ctx, to);
+	if (ctx->d_initA) {	/* bootstrap fits: the partition indicators come from the observed haplotypes (rnd_init.c:471) */
+		a.gtA = ctx->d_initA;
+		a.gtS = ctx->d_initS;
+	}
 	ctx->kt->part_p(a, ctx->stream);
 	ctx->kt->part_q(a, ctx->stream);
 	const int indiv = ctx->qstride != 0;

@@ -63,6 +63,7 @@ def load():
         "mchip_mstep_from_rand_partition": ([vp, vp, i32], i32),
         "mchip_get_genotypes": ([vp, vp], i32),
         "mchip_simulate_genotypes": ([vp, i32, i32, i32, vp, vp, i32, i32, vp, vp], i32),
+        "mchip_set_init_genotypes": ([vp, vp], i32),
         "mchip_get_expected_counts": ([vp, vp], i32),
         "mchip_secant": ([vp, i32, i32, i32, i32], i32),
         "mchip_step_dots": ([vp, i32, dp], i32),
@@ -90,7 +91,7 @@ ABI_SYMBOLS = [
     "mchip_synchronize", "mchip_set_genotypes", "mchip_set_model", "mchip_set_p", "mchip_get_p", "mchip_set_q",
     "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_em_run", "mchip_last_loglik", "mchip_e_step",
     "mchip_loglik", "mchip_loglik_prefetch", "mchip_mstep_from_partition", "mchip_mstep_from_rand_partition",
-    "mchip_get_genotypes", "mchip_simulate_genotypes",
+    "mchip_get_genotypes", "mchip_simulate_genotypes", "mchip_set_init_genotypes",
     "mchip_get_expected_counts", "mchip_secant", "mchip_step_dots",
     "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
     "mchip_profile_end", "mchip_device_info", "mchip_comm_create", "mchip_comm_all_reduce", "mchip_comm_destroy",
@@ -136,6 +137,15 @@ class Context:
         g = np.empty((self.I, self.L, self.ploidy), dtype=np.uint8)
         self._chk(self.lib.mchip_get_genotypes(self.h, g.ctypes.data))
         return g
+
+    def set_init_genotypes(self, geno):
+        """The data set hard-partition initialisations read instead of the current one (None: back to the current one)."""
+        if geno is None:
+            self._chk(self.lib.mchip_set_init_genotypes(self.h, None))
+            return
+        g = np.ascontiguousarray(geno, dtype=np.uint8)
+        assert g.shape == (self.I, self.L, self.ploidy)
+        self._chk(self.lib.mchip_set_init_genotypes(self.h, g.ctypes.data))
 
     def simulate_genotypes(self, I, L, ploidy, ua, window, K, q, p, eta_constrained=0):
         """Parametric-bootstrap data set drawn on the device (include/multiclust_hip.h); drops the model."""

@@ -20,7 +20,7 @@ class McOptions(C.Structure):
 
 class McData(C.Structure):
     _fields_ = [("I", C.c_int), ("L", C.c_int), ("ploidy", C.c_int),
-                ("uniquealleles", C.c_void_p), ("geno", C.c_void_p)]
+                ("uniquealleles", C.c_void_p), ("geno", C.c_void_p), ("init_geno", C.c_void_p)]
 
 
 class McModel(C.Structure):

@@ -130,6 +130,10 @@ static int model_create(mc_model **out, const mc_options *opt, const mc_data *da
 					      opt->eta_constrained, sim->q, sim->p);
 	else
 		rc = mchip_set_genotypes(mod->dev, dat->I, dat->L, dat->ploidy, dat->uniquealleles, dat->geno);
+	/* fits to a bootstrap data set initialise from the observed haplotypes (rnd_init.c:471): dat->geno when the data set
+	 * was generated on the device, dat->init_geno when the caller uploaded a replicate as dat->geno */
+	if (!rc && opt->admixture && (sim || dat->init_geno))
+		rc = mchip_set_init_genotypes(mod->dev, sim ? dat->geno : dat->init_geno);
 	if (rc || (rc = mchip_set_model(mod->dev, K, opt->admixture, opt->eta_constrained, opt->do_projection,
 					opt->eta_lower_bound, opt->p_lower_bound, opt->accel_scheme ? opt->q : 0))) {
 		fprintf(stderr, "ERROR [mc_em.c::mc_model_create]: %s\n", mchip_last_error(mod->dev));

@@ -51,6 +51,8 @@ typedef struct mc_data {	/* flat form of reference struct _data's genotype field
 	int I, L, ploidy;
 	const int32_t *uniquealleles;	/* [L] */
 	const uint8_t *geno;		/* [I][L][ploidy] allele indices, MCHIP_MISSING = 0xFF */
+	const uint8_t *init_geno;	/* NULL, or the observed data set while `geno` is a bootstrap replicate: the random
+					 * partition of the admixture model keeps reading dat->IL (rnd_init.c:471) */
 } mc_data;
 
 typedef struct mc_model {	/* EM-layer state of reference struct _model (multiclust.h:259-360) */

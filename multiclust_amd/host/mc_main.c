@@ -576,7 +576,7 @@ int main(int argc, const char **argv)
 	if ((rc = mc_read_structure(&o, &d))) return rc;
 	if (o.em.verbosity >= MC_TALKATIVE)
 		fprintf(stderr, "INFO: Finished reading data: %d %d-ploid individuals at %d loci.\n", d.I, d.ploidy, d.L);
-	mc_data md = { d.I, d.L, d.ploidy, d.uniquealleles, d.geno };
+	mc_data md = { d.I, d.L, d.ploidy, d.uniquealleles, d.geno, NULL };
 	/* synchronize (multiclust.c:807-893) */
 	if (mc_synchronize(&o.em, &md)) return 2;
 	if (d.I < o.max_K) { fprintf(stderr, "ERROR: Maximum number of clusters (%d) (set with command-line argument -k) cannot exceed the number of individuals (%d)\n", o.max_K, d.I); return 2; }
@@ -644,8 +644,10 @@ int main(int argc, const char **argv)
 			} else {
 				mc_bootstrap_genotypes(&o.em, &md, st.mle_K, st.mle_q, st.mle_p, &st.rng, sim);
 				md.geno = d.geno = sim;
+				md.init_geno = orig;
 				rc = estimate_model(&o, &d, &md, &st, 1, NULL, NULL);
 				md.geno = d.geno = orig;
+				md.init_geno = NULL;
 			}
 			if (rc) { free(sim); goto END; }
 			if (st.ts_bs >= st.ts_obs) ntime++;

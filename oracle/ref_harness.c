@@ -461,6 +461,19 @@ int main(int argc, const char **argv)
 					fwrite(&c, 1, 1, f);
 				}
 		fclose(f);
+		/* an initialisation while the bootstrap data set is in place (what run_bootstrap's fits start from): the random
+		 * partition reads dat->IL, which parametric_bootstrap does not replace (rnd_init.c:471) */
+		{
+			double ***alias = mod->mle_pKLM;
+			double **eta_alias = mod->mle_etaik;
+			double *etak_alias = mod->mle_etak;
+			mod->mle_pKLM = NULL; mod->mle_etaik = NULL; mod->mle_etak = NULL;
+			reset_model_state(opt, mod);		/* srand(opt->seed) */
+			if ((err = initialize_model(opt, dat, mod))) die("initialize_model (bootstrap) failed");
+			dump_q("q_bsinit.f64", opt, dat, mod, 0);
+			dump_p("p_bsinit.f64", dat, mod, 0);
+			mod->mle_pKLM = alias; mod->mle_etaik = eta_alias; mod->mle_etak = etak_alias;
+		}
 		cleanup_parametric_bootstrap(dat);
 		free(mod->mle_pKLM);
 		mod->mle_pKLM = NULL; mod->mle_etaik = NULL; mod->mle_etak = NULL;

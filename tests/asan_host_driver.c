@@ -17,6 +17,7 @@ int mchip_get_q(mchip_context*c,int s,double*p){(void)c;(void)s;(void)p;return 2
 int mchip_get_expected_counts(mchip_context*c,double*p){(void)c;(void)p;return 2;}
 int mchip_mstep_from_partition(mchip_context*c,const uint8_t*a,int t){(void)c;(void)a;(void)t;return 2;}
 int mchip_mstep_from_rand_partition(mchip_context*c,const uint32_t*a,int t){(void)c;(void)a;(void)t;return 2;}
+int mchip_set_init_genotypes(mchip_context*c,const uint8_t*g){(void)c;(void)g;return 2;}
 int mchip_get_genotypes(mchip_context*c,uint8_t*g){(void)c;(void)g;return 2;}
 int mchip_simulate_genotypes(mchip_context*c,int I,int L,int p,const int32_t*u,const uint32_t*w,int K,int e,const double*q,const double*pp){(void)c;(void)I;(void)L;(void)p;(void)u;(void)w;(void)K;(void)e;(void)q;(void)pp;return 2;}
 int mchip_em_step(mchip_context*c,int a,int b,double*l){(void)c;(void)a;(void)b;(void)l;return 2;}

@@ -83,3 +83,51 @@ def test_get_genotypes_roundtrip(ctx):
     ua, geno = make_dataset(77, 131, 3, ploidy=2, max_alleles=5, seed=1, missing=0.05)
     ctx.set_genotypes(ua, geno)
     assert np.array_equal(ctx.get_genotypes(), geno)
+
+
+def geno_from_counts(counts, ua, ploidy):
+    """genotype bytes [I][L][ploidy] with the given allele counts [I][T] (the order of copies inside a locus is free)"""
+    I, L = counts.shape[0], len(ua)
+    toff = np.concatenate([[0], np.cumsum(ua)])
+    out = np.full((I, L, ploidy), 255, dtype=np.uint8)
+    for l in range(L):
+        c = counts[:, toff[l]:toff[l + 1]]
+        fill = np.zeros(I, dtype=np.int64)
+        for m in range(c.shape[1]):
+            for rep in range(int(c[:, m].max(initial=0))):
+                rows = np.nonzero(c[:, m] > rep)[0]
+                out[rows, l, fill[rows]] = m
+                fill[rows] += 1
+    return out
+
+
+@pytest.mark.parametrize("name", ["multi_admix_k4", "tetra_admix_k3", "missing_admix_k3", "multi_admix_c_k3"])
+def test_bootstrap_fit_initialises_like_the_reference(ctx, name):
+    """While bootstrapping, the reference's random_allele_partition reads the observed haplotypes (rnd_init.c:471), so
+    the initial parameters of a fit to the simulated data equal those of a fit to the observed data for the same seed
+    (q_bsinit/p_bsinit, dumped by the harness with the bootstrap data set in place)."""
+    g = Golden(name)
+    window, _ = ob.glibc_window(g.m["bootstrap_seed"])
+    ctx.simulate_genotypes(g.I, g.L, g.ploidy, g.ua, window, g.K, g.q("bs"), g.p("bs"),
+                           eta_constrained=g.m["eta_constrained"])
+    ctx.set_init_genotypes(g.geno)
+    ctx.set_model(g.K, eta_constrained=g.m["eta_constrained"], lower_bound=g.lower_bound)
+    w0, _ = ob.glibc_window(g.m["seed"])
+    ctx.mstep_from_rand_partition(w0, 0)
+    np.testing.assert_allclose(ctx.get_q(0), g.q("bsinit"), rtol=1e-15, atol=1e-18)
+    np.testing.assert_allclose(ctx.get_p(0), g.p("bsinit"), rtol=1e-15, atol=1e-18)
+    # without the observed haplotypes the partition counts come from the simulated alleles: different parameters
+    ctx.set_init_genotypes(None)
+    ctx.mstep_from_rand_partition(w0, 1)
+    assert not np.array_equal(ctx.get_p(1), ctx.get_p(0))
+
+
+def test_bootstrap_mixture_fit_initialises_like_the_reference():
+    """The mixture model's initialisation reads the allele counts, i.e. the simulated data (rnd_init.c:192-339)."""
+    g = Golden("multi_mix_k3")
+    sim = geno_from_counts(golden_bootstrap(g), g.ua, g.ploidy)
+    fit = host.Fit(g.ua, sim, g.K, admixture=0, verbosity=1)
+    fit.initialize(g.m["seed"])
+    np.testing.assert_allclose(fit.get_q(0).ravel(), g.q("bsinit").ravel(), rtol=1e-15, atol=1e-18)
+    np.testing.assert_allclose(fit.get_p(0), g.p("bsinit"), rtol=1e-15, atol=1e-18)
+    fit.close()
