@@ -407,6 +407,8 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 	const int lb0 = l0 >> 3, lb_end = (l1 + 7) >> 3;
 	double prod = 1.0;
 	int blk = 0, ex = 0;
+	constexpr int STAGE = 2;
+	const bool staged = a.tile_cols * K <= STAGE * QBLOCK;	/* wave-uniform */
 
 	/* stage the first tile */
 	{
@@ -422,13 +424,25 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 		const int buf = (lb - lb0) & 1;
 		const double *tile = lds + (size_t)buf * a.tile_cols * KP;
 		const int c_lo = a.toff[lb * 8];
-		/* prefetch the next tile into the other buffer and the next genotype group into registers */
+		/* prefetch the next tile and the next genotype group.  Tiles of up to STAGE * QBLOCK doubles (every data set with
+		 * <= 4 alleles per locus at K <= 8) wait in registers while this block is computed and go to the other LDS buffer
+		 * after it, so no s_waitcnt for them sits in front of the arithmetic; larger tiles are copied through at once */
+		double stage[STAGE];
+		int nel_next = 0;
+		double *dst = lds + (size_t)(buf ^ 1) * a.tile_cols * KP;
 		if (lb + 1 < lb_end) {
 			const int n_lo = a.toff[(lb + 1) * 8], n_hi = a.toff[min((lb + 1) * 8 + 8, a.L)];
-			const int nel = (n_hi - n_lo) * K;
-			double *dst = lds + (size_t)(buf ^ 1) * a.tile_cols * KP;
-			for (int x = threadIdx.x; x < nel; x += QBLOCK)
-				dst[(x / K) * KP + (x % K)] = a.P[(size_t)n_lo * K + x];
+			nel_next = (n_hi - n_lo) * K;
+			const double *src = a.P + (size_t)n_lo * K;
+			if (staged) {
+#pragma unroll
+				for (int s2 = 0; s2 < STAGE; s2++) {
+					const int x = threadIdx.x + s2 * QBLOCK;
+					stage[s2] = src[min(x, nel_next - 1)];
+				}
+			} else {
+				for (int x = threadIdx.x; x < nel_next; x += QBLOCK) dst[(x / K) * KP + (x % K)] = src[x];
+			}
 		}
 		gn.load(a.gtS, (size_t)min(lb + 1, lb_end - 1) * a.I + i, pl);
 		/* the block's eight locus offsets in one scalar load (toff is padded by 8 entries), instead of one s_load + wait
@@ -514,19 +528,22 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 				}
 			}
 		};
-		if (lb * 8 + 8 <= l1) {
+		/* unrolled with a scalar bound check per locus: static j keeps the genotype group and the offsets in registers (a
+		 * dynamic index would put them in scratch, whose s_waitcnt would also wait for the prefetches) */
+		const int nloc = l1 - lb * 8;
 #pragma unroll
-			for (int j = 0; j < 8; j++) {
-				one_locus(j);
-				if (PL == 4 && j == 3) tick();
-			}
-		} else {
-			for (int j = 0; j < 8 && lb * 8 + j < l1; j++) {
-				one_locus(j);
-				if (PL == 4 && j == 3) tick();
-			}
+		for (int j = 0; j < 8; j++) {
+			if (j < nloc) one_locus(j);
+			if (PL == 4 && j == 3) tick();
 		}
 		tick();
+		if (staged) {
+#pragma unroll
+			for (int s2 = 0; s2 < STAGE; s2++) {
+				const int x = threadIdx.x + s2 * QBLOCK;
+				if (x < nel_next) dst[(x / K) * KP + (x % K)] = stage[s2];
+			}
+		}
 		g = gn;
 		__syncthreads();	/* next tile is complete and this one may be overwritten */
 	}
