@@ -297,7 +297,9 @@ def main():
                 "iteration_hbm_frac": B["iteration"] * (value / world) / 1e9 / HBM_PEAK_GBS,
                 "fp64_valu_frac": nnz_flops * (value / world) / 1e12 / FP64_VALU_PEAK_TF,
                 "fp64_note": "kernels are FP64-issue-bound, not HBM-bound: (5K+5) flop per cell x I x T per iteration over the 78.6 TF/s "
-                             "vector-FP64 spec peak (best measured v_fma_f64 rate on this chip: %.1f TF/s)" % FP64_VALU_MEASURED_TF,
+                             "vector-FP64 spec peak (best measured v_fma_f64 rate on this chip: %.1f TF/s); PMC counters of the same "
+                             "command at config 3 (profiles/r01_v4_c3_sq_counters.txt): vector ALUs busy 94 %% of the column pass, "
+                             "83 %% of the individual pass" % FP64_VALU_MEASURED_TF,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
