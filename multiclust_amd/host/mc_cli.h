@@ -41,7 +41,7 @@ typedef struct mc_cli_data {
 	int I, L, ploidy, M;		/* M = max alleles at a locus */
 	int missing_data;
 	int interleaved;
-	int *IL;			/* [I*ploidy][L] allele codes as read (reference dat->IL) */
+	int *IL;			/* [I*ploidy][L] allele codes as read (reference dat->IL); released by the reader once geno exists */
 	int32_t *uniquealleles;		/* [L] */
 	int **L_alleles;		/* [L][..] ascending real alleles (phantom slot excluded) */
 	uint8_t *geno;			/* [I][L][ploidy] allele indices, 0xFF missing */

@@ -5,13 +5,17 @@
  * interleaved layout detected from the first two names, `ploidy` consecutive lines per individual otherwise,
  * locales numbered in order of first appearance, per-locus ascending allele lists, the phantom trailing allele slot
  * for loci that have missing data (uniquealleles counts it, L_alleles does not; read_file.c:527-533 vs 581-585),
- * and the genotype in allele-index form.  Not the same cost: one pass over the file in memory and one O(n log n)
- * sort per locus instead of two O(n^2) bubble sorts per locus (read_file.c:518,577).
+ * and the genotype in allele-index form.  Not the same cost: the file is parsed in memory by several threads (lines are
+ * independent), and the per-locus allele lists are built by threads over blocks of loci with one small sorted insert
+ * list per locus instead of two O(n^2) bubble sorts over all haplotypes (read_file.c:518,577).
  */
 #include "mc_cli.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 static int fail(const char *fn, int line, const char *msg, const char *arg)
 {
@@ -52,14 +56,141 @@ static char *dup_token(const char *s, size_t len)
 	return r;
 }
 
-static int cmp_int(const void *a, const void *b)
+/* ---- worker threads ---- */
+enum { RD_OK = 0, RD_SHORT_LINE, RD_NOT_INT, RD_NO_ALLELE, RD_TOO_MANY, RD_NOMEM };
+
+typedef struct parse_job {
+	char **cur, **end;		/* per data line: first allele token / end of line */
+	size_t ln0, ln1;		/* data lines [ln0, ln1) */
+	int L, pl, interleaved, missing_value;
+	int *IL;
+	int err;
+} parse_job;
+
+/* the numeric part of data lines ln0..ln1-1 into IL (strtol semantics for well-formed tokens: optional sign, digits) */
+static void *parse_main(void *arg)
 {
-	int x = *(const int *)a, y = *(const int *)b;
-	return (x > y) - (x < y);
+	parse_job *j = arg;
+	const int per_line = j->interleaved ? j->pl : 1;
+	for (size_t ln = j->ln0; ln < j->ln1; ln++) {
+		const char *c = j->cur[ln], *end = j->end[ln];
+		const size_t h0 = j->interleaved ? ln * (size_t)j->pl : ln;
+		for (int l = 0; l < j->L; l++)
+			for (int x = 0; x < per_line; x++) {
+				while (c < end && is_space(*c)) c++;
+				if (c >= end) { j->err = RD_SHORT_LINE; return NULL; }
+				int neg = 0;
+				long v = 0;
+				if (*c == '-' || *c == '+') { neg = *c == '-'; c++; }
+				if (c >= end || *c < '0' || *c > '9') { j->err = RD_NOT_INT; return NULL; }
+				while (c < end && *c >= '0' && *c <= '9') v = v * 10 + (*c++ - '0');
+				while (c < end && !is_space(*c)) c++;		/* trailing characters of the token, as strtol leaves them */
+				if (neg) v = -v;
+				if ((int)v == j->missing_value) v = MC_MISSING;	/* change_missing_value, read_file.c:266-268 */
+				j->IL[(h0 + (size_t)x) * (size_t)j->L + (size_t)l] = (int)v;
+			}
+	}
+	return NULL;
+}
+
+typedef struct locus_job {
+	const int *IL;
+	int I, L, pl, l0, l1;
+	int32_t *uniquealleles;
+	int **L_alleles;
+	uint8_t *geno;
+	int missing_data, M, err;
+} locus_job;
+
+#define LOCUS_BLOCK 1024
+/* summarize_alleles (read_file.c:443-600) for loci l0..l1-1: ascending list of observed alleles, phantom slot when the
+ * locus has missing data, genotype bytes.  Loci are taken LOCUS_BLOCK at a time so that IL rows are read in 4 KB runs. */
+static void *locus_main(void *arg)
+{
+	locus_job *j = arg;
+	const int nhap = j->I * j->pl, L = j->L;
+	/* per locus of the block: its sorted allele list (only the first few entries of a row are ever touched for the usual
+	 * handful of alleles), its length, whether a copy is missing, the last allele seen */
+	int (*uniq)[256] = malloc(sizeof(int[256]) * LOCUS_BLOCK);
+	int *nu = malloc(sizeof(int) * 3 * LOCUS_BLOCK), *miss = nu + LOCUS_BLOCK, *last = nu + 2 * LOCUS_BLOCK;
+	if (!uniq || !nu) { free(uniq); free(nu); j->err = RD_NOMEM; return NULL; }
+	for (int b0 = j->l0; b0 < j->l1; b0 += LOCUS_BLOCK) {
+		const int nb = j->l1 - b0 < LOCUS_BLOCK ? j->l1 - b0 : LOCUS_BLOCK;
+		for (int x = 0; x < nb; x++) { nu[x] = 0; miss[x] = 0; last[x] = MC_MISSING; }
+		for (int h = 0; h < nhap; h++) {
+			const int *row = j->IL + (size_t)h * L + b0;
+			for (int x = 0; x < nb; x++) {
+				const int v = row[x];
+				if (v == MC_MISSING) { miss[x] = 1; continue; }
+				if (v == last[x] && nu[x]) continue;	/* same as the previous observed allele: already known */
+				last[x] = v;
+				int lo = 0, hi = nu[x];			/* sorted insert */
+				while (lo < hi) {
+					const int mid = (lo + hi) / 2;
+					if (uniq[x][mid] < v) lo = mid + 1; else hi = mid;
+				}
+				if (lo < nu[x] && uniq[x][lo] == v) continue;
+				if (nu[x] >= 255) { j->err = RD_TOO_MANY; free(uniq); free(nu); return NULL; }
+				memmove(&uniq[x][lo + 1], &uniq[x][lo], sizeof(int) * (size_t)(nu[x] - lo));
+				uniq[x][lo] = v;
+				nu[x]++;
+			}
+		}
+		for (int x = 0; x < nb; x++) {
+			const int l = b0 + x;
+			if (!nu[x]) { j->err = RD_NO_ALLELE; free(uniq); free(nu); return NULL; }
+			if (nu[x] > 254) { j->err = RD_TOO_MANY; free(uniq); free(nu); return NULL; }
+			if (miss[x]) j->missing_data = 1;
+			j->uniquealleles[l] = nu[x] + (miss[x] ? 1 : 0);
+			if (!(j->L_alleles[l] = malloc(sizeof(int) * (size_t)nu[x]))) { j->err = RD_NOMEM; free(uniq); free(nu); return NULL; }
+			memcpy(j->L_alleles[l], uniq[x], sizeof(int) * (size_t)nu[x]);
+			if (j->uniquealleles[l] > j->M) j->M = j->uniquealleles[l];
+		}
+		for (int i = 0; i < j->I; i++)
+			for (int a = 0; a < j->pl; a++) {
+				const int *row = j->IL + (size_t)(i * j->pl + a) * L + b0;
+				for (int x = 0; x < nb; x++) {
+					const int v = row[x];
+					uint8_t idx = MCHIP_MISSING;
+					if (v != MC_MISSING) {
+						int lo = 0, hi = nu[x] - 1;
+						while (lo < hi) {
+							const int mid = (lo + hi) / 2;
+							if (uniq[x][mid] < v) lo = mid + 1; else hi = mid;
+						}
+						idx = (uint8_t)lo;
+					}
+					j->geno[((size_t)i * L + (size_t)(b0 + x)) * (size_t)j->pl + (size_t)a] = idx;
+				}
+			}
+	}
+	free(uniq);
+	free(nu);
+	return NULL;
+}
+
+static double now_s(void)
+{
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+#define PHASE(name) do { if (timing) { double t_ = now_s(); fprintf(stderr, "INFO [mc_reader.c]: %-18s %.3f s\n", name, t_ - t_phase); t_phase = t_; } } while (0)
+
+static int n_threads(size_t work)
+{
+	long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+	int nt = cpus > 16 ? 16 : (cpus < 1 ? 1 : (int)cpus);
+	if (getenv("MC_READER_THREADS") && atoi(getenv("MC_READER_THREADS")) > 0) nt = atoi(getenv("MC_READER_THREADS"));
+	if (nt > 64) nt = 64;
+	if (work < ((size_t)1 << 20)) nt = 1;	/* small files: not worth a thread */
+	return nt;
 }
 
 int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 {
+	const int timing = getenv("MC_READER_TIMING") != NULL;
+	double t_phase = now_s();
 	FILE *f = fopen(opt->filename, "rb");
 	if (!f) return FAIL("could not open file '%s'", opt->filename);
 	fseek(f, 0, SEEK_END);
@@ -87,6 +218,7 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 		p = q + 1;
 	}
 	int rc = 1;
+	PHASE("file into memory");
 	memset(dat, 0, sizeof *dat);
 	dat->ploidy = opt->ploidy;
 	if (nlines < 3) { FAIL("file '%s' has no data lines", opt->filename); goto DONE; }
@@ -128,7 +260,6 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 	for (size_t ln = 0; ln < ndata; ln++) {
 		char *c = ls[first + ln], *end = le[first + ln];
 		const int i = dat->interleaved ? (int)ln : (int)(ln / (size_t)pl);
-		const int h0 = dat->interleaved ? i * pl : (int)ln;
 		char *name = next_token(&c, end, &len);
 		size_t llen, nlen = len;
 		char *loc = next_token(&c, end, &llen);
@@ -145,16 +276,28 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 			}
 			dat->locale[i] = found;
 		}
-		for (int l = 0; l < L; l++)
-			for (int j = 0; j < (dat->interleaved ? pl : 1); j++) {
-				char *t = next_token(&c, end, &len), *endp;
-				if (!t) { FAIL("failed to read a locus in file '%s'.  Check option -R.", opt->filename); goto DONE; }
-				long v = strtol(t, &endp, 10);
-				if (endp == t) { FAIL("non-integer allele in file '%s'", opt->filename); goto DONE; }
-				if ((int)v == opt->missing_value) v = MC_MISSING;	/* change_missing_value, read_file.c:266-268 */
-				dat->IL[(size_t)(h0 + j) * L + l] = (int)v;
-			}
+		ls[first + ln] = c;		/* from here on the line is numbers: parsed by the worker threads below */
 	}
+	PHASE("names + locales");
+	{
+		const int nt = n_threads((size_t)nhap * (size_t)L);
+		parse_job jobs[64];
+		pthread_t th[64];
+		const size_t per = (ndata + (size_t)nt - 1) / (size_t)nt;
+		int perr = RD_OK;
+		for (int t = 0; t < nt; t++) {
+			const size_t lo = (size_t)t * per, hi = lo + per < ndata ? lo + per : ndata;
+			jobs[t] = (parse_job){ ls + first, le + first, lo < ndata ? lo : ndata, hi, L, pl, dat->interleaved, opt->missing_value, dat->IL, RD_OK };
+			if (nt == 1 || pthread_create(&th[t], NULL, parse_main, &jobs[t])) { parse_main(&jobs[t]); th[t] = 0; }
+		}
+		for (int t = 0; t < nt; t++) {
+			if (th[t]) pthread_join(th[t], NULL);
+			if (!perr) perr = jobs[t].err;
+		}
+		if (perr == RD_SHORT_LINE) { FAIL("failed to read a locus in file '%s'.  Check option -R.", opt->filename); goto DONE; }
+		if (perr) { FAIL("non-integer allele in file '%s'", opt->filename); goto DONE; }
+	}
+	PHASE("parse");
 	dat->i_p = calloc((size_t)dat->numpops, sizeof *dat->i_p);
 	for (int i = 0; i < I; i++) dat->i_p[dat->locale[i]]++;
 
@@ -163,41 +306,35 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 	dat->L_alleles = calloc((size_t)L, sizeof *dat->L_alleles);
 	dat->toff = calloc((size_t)L + 1, sizeof *dat->toff);
 	dat->geno = malloc((size_t)I * L * pl);
-	int *col = malloc(sizeof(int) * (size_t)nhap);
-	if (!dat->uniquealleles || !dat->L_alleles || !dat->toff || !dat->geno || !col) { FAIL("out of memory%s", NULL); goto DONE; }
-	for (int l = 0; l < L; l++) {
-		for (int h = 0; h < nhap; h++) col[h] = dat->IL[(size_t)h * L + l];
-		qsort(col, (size_t)nhap, sizeof(int), cmp_int);
-		int nreal = 0, has_missing = 0;
-		for (int h = 0; h < nhap; h++) {
-			if (col[h] == MC_MISSING) { has_missing = 1; continue; }
-			if (!nreal || col[h] != col[nreal - 1]) col[nreal++] = col[h];	/* compact uniques in place */
+	if (!dat->uniquealleles || !dat->L_alleles || !dat->toff || !dat->geno) { FAIL("out of memory%s", NULL); goto DONE; }
+	{
+		const int nt = n_threads((size_t)nhap * (size_t)L);
+		locus_job jobs[64];
+		pthread_t th[64];
+		const int per = ((L + nt - 1) / nt + LOCUS_BLOCK - 1) / LOCUS_BLOCK * LOCUS_BLOCK;
+		int lerr = RD_OK;
+		for (int t = 0; t < nt; t++) {
+			const int lo = t * per < L ? t * per : L, hi = lo + per < L ? lo + per : L;
+			jobs[t] = (locus_job){ dat->IL, I, L, pl, lo, hi, dat->uniquealleles, dat->L_alleles, dat->geno, 0, 0, RD_OK };
+			if (nt == 1 || pthread_create(&th[t], NULL, locus_main, &jobs[t])) { locus_main(&jobs[t]); th[t] = 0; }
 		}
-		if (!nreal) { free(col); FAIL("a locus of '%s' has no observed allele", opt->filename); goto DONE; }
-		if (nreal > 254) { free(col); FAIL("a locus of '%s' has more than 254 alleles", opt->filename); goto DONE; }
-		if (has_missing) dat->missing_data = 1;
-		dat->uniquealleles[l] = nreal + (has_missing ? 1 : 0);
-		dat->L_alleles[l] = malloc(sizeof(int) * (size_t)nreal);
-		memcpy(dat->L_alleles[l], col, sizeof(int) * (size_t)nreal);
-		if (dat->uniquealleles[l] > dat->M) dat->M = dat->uniquealleles[l];
-		dat->toff[l + 1] = dat->toff[l] + dat->uniquealleles[l];
-		for (int i = 0; i < I; i++)
-			for (int a = 0; a < pl; a++) {
-				const int v = dat->IL[(size_t)(i * pl + a) * L + l];
-				uint8_t idx = MCHIP_MISSING;
-				if (v != MC_MISSING) {
-					int lo = 0, hi = nreal - 1;
-					while (lo < hi) {
-						int mid = (lo + hi) / 2;
-						if (dat->L_alleles[l][mid] < v) lo = mid + 1; else hi = mid;
-					}
-					idx = (uint8_t)lo;
-				}
-				dat->geno[((size_t)i * L + l) * pl + a] = idx;
-			}
+		for (int t = 0; t < nt; t++) {
+			if (th[t]) pthread_join(th[t], NULL);
+			if (!lerr) lerr = jobs[t].err;
+			if (jobs[t].missing_data) dat->missing_data = 1;
+			if (jobs[t].M > dat->M) dat->M = jobs[t].M;
+		}
+		if (lerr == RD_NO_ALLELE) { FAIL("a locus of '%s' has no observed allele", opt->filename); goto DONE; }
+		if (lerr == RD_TOO_MANY) { FAIL("a locus of '%s' has more than 254 alleles", opt->filename); goto DONE; }
+		if (lerr) { FAIL("out of memory%s", NULL); goto DONE; }
 	}
-	free(col);
+	for (int l = 0; l < L; l++) dat->toff[l + 1] = dat->toff[l] + dat->uniquealleles[l];
 	dat->T = dat->toff[L];
+	PHASE("alleles + genotype");
+	/* the codes as read (4 bytes per allele copy: 8 GB at config-3 size) have served their purpose: nothing downstream
+	 * reads them once the index form and the allele lists exist */
+	free(dat->IL);
+	dat->IL = NULL;
 	rc = 0;
 DONE:
 	free(ls); free(le); free(buf);
