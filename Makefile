@@ -2,7 +2,7 @@
 HIPCC   ?= /opt/rocm/bin/hipcc
 CC      ?= gcc
 ARCH    ?= gfx950
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Imulticlust_amd/csrc -Wall -Wno-unused-function
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Imulticlust_amd/csrc -Wall -Wno-unused-function $(EXTRA)
 CFLAGS   = -std=gnu11 -O2 -fPIC -Wall -Wextra -Iinclude
 
 OBJ  = build/obj

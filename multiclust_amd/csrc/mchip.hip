@@ -913,7 +913,7 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	}
 	ctx->n_ichunks = (ctx->I + ctx->ichunk - 1) / ctx->ichunk;
 	/* individual pass: slab bytes per chunk 8*K*I, genotype bytes per chunk lchunk*I*ploidy */
-	const int ind_tiles = (ctx->I + 127) / 128;
+	const int ind_tiles = (ctx->I + MCHIP_QBLOCK - 1) / MCHIP_QBLOCK;
 	int min_lchunk = (int)ceil(8.0 * K / (slab_frac * ctx->ploidy));
 	want = (target + ind_tiles - 1) / ind_tiles;
 	cap = ctx->L / (min_lchunk > 0 ? min_lchunk : 1);
@@ -926,7 +926,7 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	ctx->n_ll_ind = ind_tiles * ctx->n_lchunks;
 	{	/* the sparse individual pass stages two tiles of 8 loci of P rows in LDS: use it while they fit 64 KiB */
 		const size_t kp = (size_t)((K + 1) & ~1);
-		const size_t lds = (2 * 8 * (size_t)ctx->max_M * kp + 128) * sizeof(double);
+		const size_t lds = (2 * 8 * (size_t)ctx->max_M * kp + MCHIP_QBLOCK) * sizeof(double);
 		ctx->sparse = (ctx->max_M <= MCHIP_SPARSE_MAX_M) && lds <= 65536 && !getenv("MCHIP_FORCE_DENSE");
 	}
 	ctx->n_llpart = ctx->n_ll_col > ctx->n_ll_ind ? ctx->n_ll_col : ctx->n_ll_ind;

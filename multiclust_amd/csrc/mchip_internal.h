@@ -22,7 +22,10 @@
 #include "multiclust_hip.h"
 
 #define MCHIP_BLOCK 256
-#define MCHIP_SPARSE_MAX_M 32	/* sparse individual pass is used when no locus has more alleles than this */
+#define MCHIP_SPARSE_MAX_M 32
+#ifndef MCHIP_QBLOCK
+#define MCHIP_QBLOCK 128	/* individuals per workgroup of the individual-side kernels (lane = individual) */
+#endif	/* sparse individual pass is used when no locus has more alleles than this */
 
 enum { MCHIP_KERN_ACCUM_P = 0, MCHIP_KERN_ACCUM_Q = 1, MCHIP_KERN_LOGLIK = 2, MCHIP_KERN_COUNT = 3 };
 

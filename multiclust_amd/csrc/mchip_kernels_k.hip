@@ -304,7 +304,7 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 }
 
 /* ---------------------------------------------------------------- individual pass */
-constexpr int QBLOCK = 128;
+constexpr int QBLOCK = MCHIP_QBLOCK;
 
 template <int PL>
 __global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
