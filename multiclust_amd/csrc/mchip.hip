@@ -100,6 +100,17 @@ template <typename Tp> static void dfree(Tp *&p)
 	p = nullptr;
 }
 
+/* temporary device allocation released on every exit path of the function that owns it */
+template <typename Tp> struct scoped_dev {
+	Tp *p = nullptr;
+	scoped_dev() = default;
+	scoped_dev(const scoped_dev &) = delete;
+	scoped_dev &operator=(const scoped_dev &) = delete;
+	~scoped_dev() { if (p) (void)hipFree(p); }
+	hipError_t alloc(size_t count) { return hipMalloc((void **)&p, count * sizeof(Tp)); }
+	operator Tp *() const { return p; }
+};
+
 /* ------------------------------------------------------------------ K-independent kernels */
 
 /* raw [I][L][pl] bytes -> gtA [ceil(I/8)][L][8][pl] and gtS [ceil(L/8)][I][8][pl]; pads with 0xFF;
@@ -751,17 +762,16 @@ static int set_shape(mchip_context *ctx, int I, int L, int ploidy, const int32_t
 static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
 {
 	const int I = ctx->I, L = ctx->L, ploidy = ctx->ploidy, T = ctx->T;
-	int *d_bad = nullptr;
-	HIPCHK(hipMalloc((void **)&d_bad, sizeof(int)));
+	scoped_dev<int> d_bad;
+	HIPCHK(d_bad.alloc(1));
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
 	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_raw, I, L, ploidy, ctx->d_ua, 0,
-			   ctx->d_gtA, ctx->d_gtS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
+			   ctx->d_gtA, ctx->d_gtS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad.p);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
-	(void)hipFree(d_bad);
 	if (bad & 1) {
 		free_data(ctx);
 		return fail(ctx, MCHIP_ERR_INVALID, "genotype allele index >= uniquealleles[l]%s", nullptr);
@@ -793,12 +803,10 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	int rc = set_shape(ctx, I, L, ploidy, ua);
 	if (rc) return rc;
 	const size_t raw_bytes = (size_t)I * L * ploidy;
-	uint8_t *d_raw = nullptr;
-	HIPCHK(hipMalloc((void **)&d_raw, raw_bytes));
+	scoped_dev<uint8_t> d_raw;
+	HIPCHK(d_raw.alloc(raw_bytes));
 	HIPCHK(hipMemcpyAsync(d_raw, geno, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
-	rc = install_raw(ctx, d_raw);
-	(void)hipFree(d_raw);
-	return rc;
+	return install_raw(ctx, d_raw);
 }
 
 int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
@@ -811,23 +819,21 @@ int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
 	dfree(ctx->d_initS);
 	if (!geno) return MCHIP_OK;
 	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
-	uint8_t *d_obs = nullptr;
-	int *d_bad = nullptr;
-	HIPCHK(hipMalloc((void **)&d_obs, n));
-	HIPCHK(hipMalloc((void **)&d_bad, sizeof(int)));
+	scoped_dev<uint8_t> d_obs;
+	scoped_dev<int> d_bad;
+	HIPCHK(d_obs.alloc(n));
+	HIPCHK(d_bad.alloc(1));
 	HIPCHK(hipMalloc((void **)&ctx->d_initA, ctx->geno_bytes_A));
 	HIPCHK(hipMalloc((void **)&ctx->d_initS, ctx->geno_bytes_S));
 	HIPCHK(hipMemcpyAsync(d_obs, geno, n, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
-	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_obs, ctx->I, ctx->L, ctx->ploidy, ctx->d_ua, 0,
-			   ctx->d_initA, ctx->d_initS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
+	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_obs.p, ctx->I, ctx->L, ctx->ploidy, ctx->d_ua, 0,
+			   ctx->d_initA, ctx->d_initS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad.p);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
-	(void)hipFree(d_obs);
-	(void)hipFree(d_bad);
 	if (bad & 1) {
 		dfree(ctx->d_initA);
 		dfree(ctx->d_initS);
@@ -842,13 +848,12 @@ int mchip_get_genotypes(mchip_context *ctx, uint8_t *geno)
 	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "no genotypes set%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
-	uint8_t *d_raw = nullptr;
-	HIPCHK(hipMalloc((void **)&d_raw, n));
-	hipLaunchKernelGGL(k_unlayout, dim3(nblk(n)), dim3(256), 0, ctx->stream, ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, d_raw);
+	scoped_dev<uint8_t> d_raw;
+	HIPCHK(d_raw.alloc(n));
+	hipLaunchKernelGGL(k_unlayout, dim3(nblk(n)), dim3(256), 0, ctx->stream, ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, d_raw.p);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(geno, d_raw, n, hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
-	(void)hipFree(d_raw);
 	return MCHIP_OK;
 }
 
@@ -1225,17 +1230,16 @@ static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to)
 	int rc;
 	if (!ctx->d_asA) HIPCHK(hipMalloc((void **)&ctx->d_asA, ctx->geno_bytes_A));
 	if (!ctx->d_asS) HIPCHK(hipMalloc((void **)&ctx->d_asS, ctx->geno_bytes_S));
-	int *d_bad = nullptr;
-	HIPCHK(hipMalloc((void **)&d_bad, sizeof(int)));
+	scoped_dev<int> d_bad;
+	HIPCHK(d_bad.alloc(1));
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
 	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_raw, ctx->I, ctx->L, ctx->ploidy,
-			   (const int32_t *)nullptr, ctx->K, ctx->d_asA, ctx->d_asS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
+			   (const int32_t *)nullptr, ctx->K, ctx->d_asA, ctx->d_asS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad.p);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
-	(void)hipFree(d_bad);
 	if (bad) return fail(ctx, MCHIP_ERR_INVALID, "partition assignment >= K%s", nullptr);
 
 	mchip_pass_args a = pass_args(ctx, to);
@@ -1273,12 +1277,10 @@ int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t raw_bytes = (size_t)ctx->I * ctx->L * ctx->ploidy;
-	uint8_t *d_raw = nullptr;
-	HIPCHK(hipMalloc((void **)&d_raw, raw_bytes));
+	scoped_dev<uint8_t> d_raw;
+	HIPCHK(d_raw.alloc(raw_bytes));
 	HIPCHK(hipMemcpyAsync(d_raw, assign, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
-	rc = partition_mstep(ctx, d_raw, to);
-	(void)hipFree(d_raw);
-	return rc;
+	return partition_mstep(ctx, d_raw, to);
 }
 
 /* (a * b) mod (x^31 - x^28 - 1) over Z/2^32 */
@@ -1377,22 +1379,19 @@ int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const
 	size_t n_chunks, n_blocks;
 	if ((rc = rng_stream_setup(ctx, window, 2 * n_copies, &base, &n_chunks, &n_blocks))) return rc;
 	const size_t nq = eta_constrained ? (size_t)K : (size_t)I * K, np = (size_t)K * ctx->T;
-	double *d_q = nullptr, *d_p = nullptr;
-	uint8_t *d_raw = nullptr;
-	HIPCHK(hipMalloc((void **)&d_q, nq * sizeof(double)));
-	HIPCHK(hipMalloc((void **)&d_p, np * sizeof(double)));
-	HIPCHK(hipMalloc((void **)&d_raw, n_chunks * (RNG_CHUNK / 2)));
+	scoped_dev<double> d_q, d_p;
+	scoped_dev<uint8_t> d_raw;
+	HIPCHK(d_q.alloc(nq));
+	HIPCHK(d_p.alloc(np));
+	HIPCHK(d_raw.alloc(n_chunks * (RNG_CHUNK / 2)));
 	HIPCHK(hipMemcpyAsync(d_q, q, nq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(d_p, p, np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	hipLaunchKernelGGL(k_simulate_admixture, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, base, ctx->d_jump_hi,
-			   ctx->d_jump_lo, n_chunks, n_copies, L, ploidy, K, ctx->T, ctx->d_toff, d_q, eta_constrained ? 0 : K, d_p,
-			   (uint32_t *)d_raw);
-	hipError_t e = hipGetLastError();
-	rc = MCHIP_OK;
-	if (e != hipSuccess) rc = fail(ctx, MCHIP_ERR_HIP, "k_simulate_admixture launch failed: %s", hipGetErrorString(e));
-	if (!rc) rc = install_raw(ctx, d_raw);
-	(void)hipStreamSynchronize(ctx->stream);
-	(void)hipFree(d_q); (void)hipFree(d_p); (void)hipFree(d_raw);
+			   ctx->d_jump_lo, n_chunks, n_copies, L, ploidy, K, ctx->T, ctx->d_toff, d_q.p, eta_constrained ? 0 : K, d_p.p,
+			   (uint32_t *)d_raw.p);
+	HIPCHK(hipGetLastError());
+	rc = install_raw(ctx, d_raw);
+	(void)hipStreamSynchronize(ctx->stream);	/* the temporaries go out of scope */
 	return rc;
 }
 

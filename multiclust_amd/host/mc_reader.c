@@ -206,13 +206,20 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 	/* split into non-empty lines */
 	size_t nlines = 0, cap = 1024;
 	char **ls = malloc(cap * sizeof *ls), **le = malloc(cap * sizeof *le);
+	if (!ls || !le) { free(ls); free(le); free(buf); return FAIL("out of memory reading '%s'", opt->filename); }
 	for (char *p = buf, *eof = buf + fsz + 1; p < eof;) {
 		char *q = memchr(p, '\n', (size_t)(eof - p));
 		if (!q) q = eof;
 		char *s = p;
 		while (s < q && is_space(*s)) s++;
 		if (s < q) {
-			if (nlines == cap) { cap *= 2; ls = realloc(ls, cap * sizeof *ls); le = realloc(le, cap * sizeof *le); }
+			if (nlines == cap) {
+				char **ls2 = realloc(ls, 2 * cap * sizeof *ls), **le2 = ls2 ? realloc(le, 2 * cap * sizeof *le) : NULL;
+				if (ls2) ls = ls2;
+				if (le2) le = le2;
+				if (!ls2 || !le2) { free(ls); free(le); free(buf); return FAIL("out of memory reading '%s'", opt->filename); }
+				cap *= 2;
+			}
 			ls[nlines] = p; le[nlines] = q; nlines++;
 		}
 		p = q + 1;
@@ -270,7 +277,9 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 			for (int n = 0; n < dat->numpops; n++)
 				if (strlen(dat->pops[n]) == llen && !strncmp(dat->pops[n], loc, llen)) { found = n; break; }
 			if (found < 0) {
-				dat->pops = realloc(dat->pops, sizeof *dat->pops * (size_t)(dat->numpops + 1));
+				char **pops2 = realloc(dat->pops, sizeof *dat->pops * (size_t)(dat->numpops + 1));
+				if (!pops2) { FAIL("out of memory%s", NULL); goto DONE; }
+				dat->pops = pops2;
 				dat->pops[dat->numpops] = dup_token(loc, llen);
 				found = dat->numpops++;
 			}
