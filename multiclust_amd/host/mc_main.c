@@ -195,7 +195,25 @@ typedef struct run_state {
 	int mle_K;
 	mc_rng rng;
 	FILE *out;			/* stdout, or a replicate's buffer when bootstrap replicates run on several devices */
+	mchip_comm **comm;		/* the run's RCCL communicator over devices device..device+n_gpus-1, created on first use */
 } run_state;
+
+/* one communicator per run: creating it (ncclCommInitAll) costs seconds, an exchange microseconds */
+static int get_comm(const mc_cli_options *o, run_state *st, mchip_comm **out)
+{
+	int rc = 0;
+	if (!*st->comm) {
+		const int n_dev = o->n_gpus < 1 ? 1 : o->n_gpus;
+		int *devs = malloc(sizeof(int) * (size_t)n_dev);
+		if (!devs) return MCHIP_ERR_ALLOC;
+		for (int x = 0; x < n_dev; x++) devs[x] = o->device + x;
+		rc = mchip_comm_create(st->comm, n_dev, devs);
+		free(devs);
+		if (rc) fprintf(stderr, "ERROR [mc_main.c]: cannot create the RCCL communicator (status %d)\n", rc);
+	}
+	*out = *st->comm;
+	return rc;
+}
 
 static void print_model_state(const mc_cli_options *o, const mc_cli_data *d, const run_state *st, int K, int diff, int newline)
 {
@@ -382,7 +400,7 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 			row[4] = res[u].iter_stop; row[5] = res[u].pindex; row[6] = res[u].fatal; row[7] = res[u].seconds_run; row[8] = 1.0;
 		}
 	}
-	if ((rc = mchip_comm_create(&comm, n_dev, devs))) { fprintf(stderr, "ERROR [mc_main.c]: cannot create the RCCL communicator (status %d)\n", rc); goto DONE; }
+	if ((rc = get_comm(o, st, &comm))) goto DONE;
 	if ((rc = mchip_comm_all_reduce(comm, tab, n_units * RES_FIELDS, 0))) { fprintf(stderr, "ERROR [mc_main.c]: %s\n", mchip_comm_last_error(comm)); goto DONE; }
 	for (int x = 1; x < n_dev; x++)
 		if (memcmp(tab[0], tab[x], sizeof(double) * (size_t)n_units * RES_FIELDS)) { fprintf(stderr, "ERROR [mc_main.c]: devices disagree after the all-reduce\n"); rc = MCHIP_ERR_STATE; goto DONE; }
@@ -420,7 +438,6 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 		}
 	}
 DONE:
-	if (comm) mchip_comm_destroy(comm);
 	if (w) for (int x = 0; x < n_dev; x++) { free(w[x].q); free(w[x].p); free(w[x].sik); }
 	if (tab) for (int x = 0; x < n_dev; x++) free(tab[x]);
 	free(w); free(th); free(res); free(tab); free(devs); free(count_K);
@@ -547,7 +564,7 @@ static int run_bootstrap_sharded(const mc_cli_options *o, const mc_cli_data *d, 
 		if (!(tab[x] = calloc((size_t)B * 2, sizeof(double)))) { rc = MCHIP_ERR_ALLOC; goto DONE; }
 		for (int b = x; b < B; b += n_dev) { tab[x][2 * b] = ts[b]; tab[x][2 * b + 1] = 1.0; }
 	}
-	if ((rc = mchip_comm_create(&comm, n_dev, devs))) { fprintf(stderr, "ERROR [mc_main.c]: cannot create the RCCL communicator (status %d)\n", rc); goto DONE; }
+	if ((rc = get_comm(o, st, &comm))) goto DONE;
 	if ((rc = mchip_comm_all_reduce(comm, tab, B * 2, 0))) { fprintf(stderr, "ERROR [mc_main.c]: %s\n", mchip_comm_last_error(comm)); goto DONE; }
 	for (int b = 0; b < B; b++) {
 		if (tab[0][2 * b + 1] != 1.0) { fprintf(stderr, "ERROR [mc_main.c]: bootstrap replicate %d was fitted %g times\n", b, tab[0][2 * b + 1]); rc = MCHIP_ERR_STATE; goto DONE; }
@@ -558,7 +575,6 @@ static int run_bootstrap_sharded(const mc_cli_options *o, const mc_cli_data *d, 
 	}
 	*ntime_out = ntime;
 DONE:
-	if (comm) mchip_comm_destroy(comm);
 	if (tab) for (int x = 0; x < n_dev; x++) free(tab[x]);
 	if (text) for (int b = 0; b < B; b++) free(text[b]);
 	free(w); free(th); free(ts); free(tab); free(text); free(devs);
@@ -585,6 +601,8 @@ int main(int argc, const char **argv)
 	if (!o.target_ll && !o.target_revisit && !o.em.n_seconds && !o.n_init) o.n_init = 1;
 	memset(&st, 0, sizeof st);
 	st.out = stdout;
+	mchip_comm *run_comm = NULL;
+	st.comm = &run_comm;
 	if (o.n_bootstrap) { st.null_K = o.max_K - 1; st.alt_K = o.max_K; }
 	/* the reference seeds libc only when -r is given; otherwise rand() runs from glibc's default seed 1 although the
 	 * banner prints 1234567 */
@@ -658,6 +676,7 @@ int main(int argc, const char **argv)
 		printf("p-value to reject H0: K=%d is %f\n", st.null_K, (double)(ntime / o.n_bootstrap));
 	}
 END:
+	if (run_comm) mchip_comm_destroy(run_comm);
 	free(st.mle_q); free(st.mle_p);
 	mc_free_data(&d);
 	return rc;
