@@ -149,6 +149,11 @@ def main():
     run("multi_mix_k3", multi, 10, "1,2,3,10", 3, ["-k", "3", "-r", "5", "-s", "3"])
     run("multi_admix_c_k3", multi, 10, "1,2,3,10", 3, ["-a", "-c", "-k", "3", "-r", "5", "-s", "3"])
     run("missing_mix_k2", miss, 5, "1,5", 0, ["-k", "2", "-r", "5"])
+    # tight convergence (-E 1e-10), plain EM: the destination of a fit, not its stopping point on a slow tail, is what is
+    # compared.  (With -s 3 at this tolerance the reference itself stops: a rounding-level decrease of the log likelihood
+    # between two EM steps makes stop() call exit(0), em_alg.c:112-120.)
+    run("c1_admix_k3_tight", c1, 1, "1", 0, ["-a", "-k", "3", "-r", "1234567", "-E", "1e-10"], keep_ilm=False)
+    run("multi_admix_k4_tight", multi, 1, "1", 0, ["-a", "-k", "4", "-r", "7", "-E", "1e-10"], keep_ilm=False)
 
     # reader-only fixtures: interleaved layout + "-1" line; remapped missing code
     inter = os.path.join(data, "multi_interleaved.stru")

@@ -38,6 +38,26 @@ def test_em_to_convergence(name):
     fit.close()
 
 
+@pytest.mark.parametrize("name", ["c1_admix_k3_tight", "multi_admix_k4_tight"])
+def test_long_em_run_stays_on_the_reference_trajectory(name):
+    """-E 1e-10: the reference iterates 11 469 / 19 212 times.  At that tolerance the stopping iteration is decided by
+    the last bits of the log likelihood (the reference stops when two successive sequential sums happen to agree to
+    1e-10; with tree-ordered sums the same tail runs a few thousand iterations longer and ends 4e-6 higher), so the
+    comparison is made at the reference's own iteration count: after that many EM iterations the log likelihood agrees
+    within 1e-8 absolute and Q/P within 1e-6 relative (north_star's tolerances)."""
+    g = Golden(name)
+    n = g.m["em_run_n_iter"]
+    fit = make_fit(g, abs_error=g.m["abs_error"], max_iter=n - 1)     # -T n runs n + 1 iterations (em_alg.c:150)
+    fit.em()
+    m = fit.mod
+    assert m.fatal == 0 and m.n_iter == n and m.iter_stop == 1
+    assert abs(m.logL - g.m["em_run_logL"]) <= 1e-8, (m.logL, g.m["em_run_logL"])
+    np.testing.assert_allclose(fit.get_q(m.pindex), g.q("emrun"), rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(fit.get_p(m.pindex), g.p("emrun"), rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(fit.expected_counts(), g.sik("emrun"), rtol=1e-6, atol=1e-9)
+    fit.close()
+
+
 @pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "multi_admix_k4_s1", "multi_admix_k4_s2",
                                   "multi_admix_k3_qn1", "tetra_admix_k3", "missing_admix_k3", "multi_admix_c_k3"])
 def test_accelerated_cycles_trace(name):
