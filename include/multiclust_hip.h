@@ -26,7 +26,7 @@ extern "C" {
 
 #define MCHIP_ABI_VERSION 1
 #define MCHIP_MISSING 0xFF	/* genotype byte for a missing allele copy (reference MISSING = -9, multiclust.h:140) */
-#define MCHIP_MAX_K 32		/* clusters supported by the K-specialised kernels (tuned for K <= 16) */
+#define MCHIP_MAX_K 32		/* clusters supported by the K-specialised kernels (cost ~ 2K+6 per cell up to K ~ 20) */
 #define MCHIP_MAX_SECANTS 3	/* options::q <= 3 without LAPACK (multiclust.c:847-851) */
 
 enum mchip_status {

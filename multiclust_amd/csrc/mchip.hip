@@ -930,7 +930,7 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	ctx->n_ll_col = col_tiles * ctx->n_ichunks;
 	ctx->n_ll_ind = ind_tiles * ctx->n_lchunks;
 	{	/* the sparse individual pass stages two tiles of 8 loci of P rows in LDS: use it while they fit 64 KiB */
-		const size_t kp = (size_t)((K + 1) & ~1);
+		const size_t kp = (size_t)(((K + 1) & ~1) + ((K % 16 == 0) ? 2 : 0));	/* KP of mchip_kernels_k.hip */
 		const size_t lds = (2 * 8 * (size_t)ctx->max_M * kp + MCHIP_QBLOCK) * sizeof(double);
 		ctx->sparse = (ctx->max_M <= MCHIP_SPARSE_MAX_M) && lds <= 65536 && !getenv("MCHIP_FORCE_DENSE");
 	}

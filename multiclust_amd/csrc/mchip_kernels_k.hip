@@ -52,6 +52,15 @@ __device__ __forceinline__ void rcp4(const double (&t)[4], double (&rc)[4])
 	rc[3] = r23 * t[2];
 }
 
+__device__ __forceinline__ void rcp_group(const double (&t)[4], double (&rc)[4]) { rcp4(t, rc); }
+__device__ __forceinline__ void rcp_group(const double (&t)[2], double (&rc)[2])
+{
+	const double rp = rcp_full(t[0] * t[1]);
+	rc[0] = rp * t[1];
+	rc[1] = rp * t[0];
+}
+__device__ __forceinline__ void rcp_group(const double (&t)[1], double (&rc)[1]) { rc[0] = rcp_full(t[0]); }
+
 /* genotype bytes of sub-entry j (0..7) of an 8-entry group; PL = 2 fast path keeps the group in a uint4 */
 template <int PL> struct geno_group;
 
@@ -245,6 +254,8 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 	constexpr int PERWORD = 32 / BITS;		/* individuals per dword */
 	constexpr int G = 4 * PERWORD;			/* individuals per 16-byte word */
 	constexpr unsigned MASK = (1u << BITS) - 1u;
+	/* individuals per inner step: their q rows must fit the scalar register file (2K SGPRs each, about 100 usable) */
+	constexpr int NJ = K <= 12 ? 4 : (K <= 20 ? 2 : 1);
 	const int c_raw = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
 	const bool valid = c_raw < a.T;
 	const int c = valid ? c_raw : a.T - 1;
@@ -265,33 +276,33 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 		for (int wi = 0; wi < 4; wi++) {
 			unsigned word = (wi == 0) ? w.x : (wi == 1) ? w.y : (wi == 2) ? w.z : w.w;
 #pragma unroll 1
-			for (int h = 0; h < PERWORD / 4; h++) {
-				const int ibase = g * G + wi * PERWORD + h * 4;
+			for (int h = 0; h < PERWORD / NJ; h++) {
+				const int ibase = g * G + wi * PERWORD + h * NJ;
 				if (ibase >= i1) break;		/* wave-uniform; padded individuals have zero counts anyway */
-				/* four individuals at a time: their q rows are wave-uniform (s_load_dwordx16 each) */
-				const double *__restrict__ q[4];
-				double n[4], t[4], rc[4];
+				/* NJ individuals at a time: their q rows are wave-uniform (scalar loads, used as SGPR operands) */
+				const double *__restrict__ q[NJ];
+				double n[NJ], t[NJ], rc[NJ];
 #pragma unroll
-				for (int j = 0; j < 4; j++) {
+				for (int j = 0; j < NJ; j++) {
 					q[j] = a.Q + (size_t)min(ibase + j, a.I - 1) * a.qstride;
 					n[j] = (double)((word >> (BITS * j)) & MASK);
 				}
 				if (!MIX) {
 #pragma unroll
-					for (int j = 0; j < 4; j++) {
+					for (int j = 0; j < NJ; j++) {
 						t[j] = q[j][0] * p[0];
 #pragma unroll
 						for (int k = 1; k < K; k++) t[j] = __builtin_fma(q[j][k], p[k], t[j]);
 					}
-					rcp4(t, rc);
+					rcp_group(t, rc);
 				}
 #pragma unroll
-				for (int j = 0; j < 4; j++) {
+				for (int j = 0; j < NJ; j++) {
 					const double r = MIX ? n[j] : n[j] * rc[j];
 #pragma unroll
 					for (int k = 0; k < K; k++) acc[k] = __builtin_fma(q[j][k], r, acc[k]);
 				}
-				word >>= 4 * BITS;
+				word >>= NJ * BITS;
 			}
 		}
 		w = wn;
@@ -371,7 +382,9 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
  * ds_read_b128; rows of one locus are consecutive, so lanes on different alleles hit different bank groups.
  * Produces the S-side sums and the log likelihood (one multiply per copy, no selects).  ACCUM = false is the
  * stand-alone log-likelihood pass (logL_admixture, log_likelihood.c:96-147). */
-constexpr int KP = (K + 1) & ~1;	/* LDS row stride in doubles: rows stay 16-byte aligned */
+/* LDS row stride in doubles: rows stay 16-byte aligned; a stride of 128 or 256 bytes would put the rows of a locus on the
+ * same banks (64 banks x 4 bytes), so K = 16 and K = 32 get two doubles of padding */
+constexpr int KP = ((K + 1) & ~1) + ((K % 16 == 0) ? 2 : 0);
 
 #ifndef MCHIP_SPARSE_WAVES
 #define MCHIP_SPARSE_WAVES 1
