@@ -16,7 +16,8 @@ log likelihood at the end (inside the timed region).  scaling = "weak".
 
 Also reported on the same JSON line: `roofline` for the dominant kernel (HIP events on the library's own
 stream) and `cpu_baseline` (the CPU oracle, timed on a bounded sample on rank 0 at N = 1 only; the oracle is
-used here only as the baseline, never as the measured path).
+used here only as the baseline, never as the measured path).  `cpu_baseline.parity` is the metric's "logL delta vs ref":
+the HIP path run on that same sample from the same parameters for the same iterations, against the oracle's result.
 """
 import argparse
 import ctypes as C
@@ -92,7 +93,7 @@ def algorithmic_bytes(w, T):
     }
 
 
-def cpu_baseline(w, ua, geno, accel, budget_s=20.0):
+def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0):
     """The CPU oracle (oracle/mc_oracle.c, fused order, one host core) on a bounded sample of the same
     workload: the first L_s loci of every individual, sized for about `budget_s` seconds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -120,11 +121,28 @@ def cpu_baseline(w, ua, geno, accel, budget_s=20.0):
             mod.em_step()
     dt = time.perf_counter() - t0
     it_s_sample = mod.n_iter / dt
+    # the same sample, parameters and iterations through the HIP path: "logL delta vs ref" of BASELINE.json's metric,
+    # measured in this run (the oracle is the checker here, as in tests/)
+    from multiclust_amd import host
+    fit = host.Fit(ua_s, geno_s, K, device=device, admixture=1, accel_scheme=accel, verbosity=1, abs_error=1e-300)
+    fit.set_params(q0, p0)
+    for _ in range(iters // 2 if accel else iters):
+        fit.accelerated_em_step() if accel else fit.em_step()
+    gq, gp = fit.get_q(fit.mod.pindex), fit.get_p(fit.mod.pindex)
+    oq, op = mod.q(mod.pindex), mod.p(mod.pindex)
+    big_q, big_p = oq > 1e-6, op > 1e-6
+    parity = {
+        "abs_dlogL": abs(fit.mod.logL - mod.logL), "rel_dlogL": abs(fit.mod.logL - mod.logL) / abs(mod.logL),
+        "max_rel_dQ": float(np.max(np.abs(gq - oq)[big_q] / oq[big_q])), "max_rel_dP": float(np.max(np.abs(gp - op)[big_p] / op[big_p])),
+        "same_n_iter": int(fit.mod.n_iter == mod.n_iter),
+        "note": "HIP path vs CPU oracle on the cpu_baseline sample, same parameters and iterations; Q/P entries > 1e-6",
+    }
+    fit.close()
     return {
         "value": it_s_sample * Ls / L, "unit": "EM iterations/s", "cores": 1, "kind": "port",
         "sample": "first %d of %d loci, all %d individuals, %d EM iterations (%s) in %.1f s on one core; "
                   "scaled by %d/%d (cost is linear in loci)" % (Ls, L, I, mod.n_iter, "SQUAREM-3 cycles" if accel else "plain EM", dt, Ls, L),
-        "sample_value": it_s_sample,
+        "sample_value": it_s_sample, "parity": parity,
     }
 
 
@@ -303,7 +321,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget, local_rank)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     fit.close()
     if rank == 0:
