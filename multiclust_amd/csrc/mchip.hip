@@ -897,13 +897,15 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	 * the grid's last partial "round" of workgroups runs at low occupancy: measured at config 3, 8 workgroups
 	 * per CU cost 6.9 ms per EM step, 64 per CU 5.4 ms (profiles/r01_geometry_sweep.txt).  More chunks mean
 	 * more partial-sum slabs (Apart/Spart are written and re-read once per step), so the chunk count is capped
-	 * where the slab bytes reach ~15 % of the genotype bytes the pass streams.  Chunk sizes are multiples of 8. */
+	 * where the slab bytes reach ~30 % of the genotype bytes the pass streams (config 2: 0.188 -> 0.179 ms per step against 15 %;
+	 * config 3 reaches its 64 workgroups per CU before either cap).  Chunk sizes are multiples of 8. */
 	int per_cu = 64;
 	if (const char *e = getenv("MCHIP_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;	/* tuning knob */
 	const int target = per_cu * ctx->n_cu;
 	const int col_tiles = (ctx->T + MCHIP_BLOCK - 1) / MCHIP_BLOCK;
 	const int iblocks = (ctx->I + 7) / 8, lblocks = (ctx->L + 7) / 8;
-	const double slab_frac = 0.15;
+	double slab_frac = 0.3;
+	if (const char *e = getenv("MCHIP_SLAB_FRAC")) slab_frac = atof(e) > 0 ? atof(e) : slab_frac;	/* tuning knob */
 	/* column pass: slab bytes per chunk 8*K*T, genotype bytes per chunk ichunk*L*ploidy */
 	int min_ichunk = (int)ceil(8.0 * K * ctx->T / (slab_frac * ctx->L * ctx->ploidy));
 	int want = (target + col_tiles - 1) / col_tiles;
