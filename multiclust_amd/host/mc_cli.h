@@ -35,6 +35,8 @@ typedef struct mc_cli_options {
 	int parallel;			/* -M */
 	int device;			/* --device (extension): HIP device index */
 	int n_gpus;			/* --gpus (extension): shard initialisations over devices device..device+n_gpus-1 */
+	int n_streams;			/* --streams (extension): concurrent fits per device, each with its own context and
+					 * stream; small data sets do not fill a GPU with one fit */
 } mc_cli_options;
 
 typedef struct mc_cli_data {

@@ -8,7 +8,7 @@
  * (618-627), print_model_state (718-793), run_bootstrap (675-708) and the -w repetition summary (201-347).
  * Deliberately absent (documented in DESIGN.md): -I/-I1 (allele-index mode gives different numbers from default
  * mode in the reference itself), --impute, --simulate, -x (not implemented in the reference either), -A, -P/-Q.
- * Extensions: --device <n> selects the HIP device; --gpus <n> shards the initialisations of each K over n GPUs of
+ * Extensions: --device <n> selects the HIP device; --streams <n> runs n fits at a time per GPU; --gpus <n> shards the initialisations of each K over n GPUs of
  * the node (one host thread and one context per GPU, units u = d, d+n, ..., each starting from the serial program's
  * rand() position by jump-ahead), with a single RCCL all-reduce of the per-unit result table, after which the serial
  * bookkeeping is replayed in unit order (admixture model, fixed number of initialisations).
@@ -45,7 +45,8 @@ static void usage(FILE *fp, const char *prog)
 		"  -d <dir> -o <stem>  output directory / file stem      -R  R-formatted STRUCTURE file\n"
 		"  --missing <n> missing-data code (default -9)           -M  print only the maximum log likelihood\n"
 		"  -v [level]    verbosity                                --device <n>  HIP device index\n"
-		"  --gpus <n>    shard the initialisations over n GPUs (admixture; one RCCL all-reduce of the results)\n", prog);
+		"  --gpus <n>    shard the initialisations over n GPUs (admixture; one RCCL all-reduce of the results)\n"
+		"  --streams <n> n concurrent fits per GPU, each on its own stream (small data sets do not fill a GPU)\n", prog);
 }
 
 static int arg_int(int argc, const char **argv, int i, long *out)
@@ -79,6 +80,7 @@ static void defaults(mc_cli_options *o)
 	o->write_files = 1;
 	o->compact = 1;
 	o->n_gpus = 1;
+	o->n_streams = 1;
 }
 
 #define BAD(msg) do { fprintf(stderr, "ERROR [mc_main.c::parse_options]: %s (argument '%s'); try -h\n", msg, i < argc ? argv[i] : ""); return 2; } while (0)
@@ -145,6 +147,7 @@ static int parse_options(mc_cli_options *o, int argc, const char **argv)
 		case 'x': BAD("-x (block relaxation) is not implemented, as in the reference");
 		case 's':
 			if (!strncmp(w, "si", 2)) BAD("--simulate is not supported by this build");
+			if (!strncmp(w, "st", 2)) { if (arg_int(argc, argv, ++i, &v) || v < 1 || v > 16) BAD("--streams"); o->n_streams = (int)v; break; }
 			if (arg_int(argc, argv, ++i, &v) || v < 0 || v > 6) BAD("-s");
 			o->em.accel_scheme = (int)v;
 			break;
@@ -197,6 +200,15 @@ typedef struct run_state {
 	FILE *out;			/* stdout, or a replicate's buffer when bootstrap replicates run on several devices */
 	mchip_comm **comm;		/* the run's RCCL communicator over devices device..device+n_gpus-1, created on first use */
 } run_state;
+
+/* sharded runs use n_gpus * n_streams workers (host thread + context + stream each); worker x sits on device
+ * device + x % n_gpus, so consecutive units land on different GPUs first */
+static int n_workers(const mc_cli_options *o) { return (o->n_gpus < 1 ? 1 : o->n_gpus) * (o->n_streams < 1 ? 1 : o->n_streams); }
+static int worker_device(const mc_cli_options *o, int x) { return o->device + x % (o->n_gpus < 1 ? 1 : o->n_gpus); }
+
+/* with one GPU its table is already complete (the workers are threads of this process); the rehearsal of the sharded
+ * path on one GPU (MC_FORCE_SHARDED) still goes through RCCL */
+static int exchange_needed(const mc_cli_options *o) { return o->n_gpus > 1 || getenv("MC_FORCE_SHARDED") != NULL; }
 
 /* one communicator per run: creating it (ncclCommInitAll) costs seconds, an exchange microseconds */
 static int get_comm(const mc_cli_options *o, run_state *st, mchip_comm **out)
@@ -332,8 +344,9 @@ static void *shard_main(void *arg)
 	mc_model *mod = NULL;
 	w->best_logL = -INFINITY;
 	w->best_unit = -1;
-	if ((w->rc = w->sim ? mc_model_create_simulated(&mod, &w->o->em, w->md, w->K, w->o->device + w->index, w->sim)
-			    : mc_model_create(&mod, &w->o->em, w->md, w->K, w->o->device + w->index))) return NULL;
+	const int device = worker_device(w->o, w->index);
+	if ((w->rc = w->sim ? mc_model_create_simulated(&mod, &w->o->em, w->md, w->K, device, w->sim)
+			    : mc_model_create(&mod, &w->o->em, w->md, w->K, device))) return NULL;
 	const clock_t start = clock();
 	for (int u = w->index; u < w->n_units; u += w->n_dev) {
 		mc_rng rng = w->base;
@@ -366,7 +379,7 @@ static void *shard_main(void *arg)
 static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, int K, run_state *st, int bootstrap,
 				       const mc_simulation *sim)
 {
-	const int n_dev = o->n_gpus, n_units = (K == 1) ? 1 : o->n_init;
+	const int n_dev = n_workers(o), n_gpus = o->n_gpus < 1 ? 1 : o->n_gpus, n_units = (K == 1) ? 1 : o->n_init;
 	const int nq = (o->em.admixture && !o->em.eta_constrained) ? d->I * K : K;
 	const int npar = mc_no_parameters(&o->em, md, K);
 	const int keep_mle = !bootstrap && o->n_bootstrap && K == st->null_K;
@@ -374,35 +387,36 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 	shard_worker *w = calloc((size_t)n_dev, sizeof *w);
 	pthread_t *th = calloc((size_t)n_dev, sizeof *th);
 	mc_unit_result *res = calloc((size_t)n_units, sizeof *res);
-	double **tab = calloc((size_t)n_dev, sizeof *tab);
-	int *devs = calloc((size_t)n_dev, sizeof *devs), *count_K = calloc((size_t)K, sizeof *count_K), rc = 0;
+	double **tab = calloc((size_t)n_gpus, sizeof *tab);
+	int *count_K = calloc((size_t)K, sizeof *count_K), rc = 0;
 	mchip_comm *comm = NULL;
-	if (!w || !th || !res || !tab || !devs || !count_K) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+	if (!w || !th || !res || !tab || !count_K) { rc = MCHIP_ERR_ALLOC; goto DONE; }
 	for (int x = 0; x < n_dev; x++) {
 		w[x].o = o; w[x].d = d; w[x].md = md; w[x].K = K; w[x].index = x; w[x].n_dev = n_dev; w[x].n_units = n_units;
 		w[x].want_params = keep_mle || (!bootstrap && o->write_files);
 		w[x].sim = sim;
 		w[x].base = st->rng; w[x].draws = mc_draws_per_init(&o->em, md, K); w[x].res = res;
-		devs[x] = o->device + x;
-		if (pthread_create(&th[x], NULL, shard_main, &w[x])) { rc = MCHIP_ERR_ALLOC; n_units ? (void)0 : (void)0; }
+		if (pthread_create(&th[x], NULL, shard_main, &w[x])) { shard_main(&w[x]); th[x] = 0; }
 	}
-	for (int x = 0; x < n_dev; x++) pthread_join(th[x], NULL);
+	for (int x = 0; x < n_dev; x++) if (th[x]) pthread_join(th[x], NULL);
 	for (int x = 0; x < n_dev; x++) if (w[x].rc) rc = w[x].rc;
 	if (rc) goto DONE;
 	mc_rng_jump(&st->rng, (uint64_t)n_units * w[0].draws);	/* where the serial stream stands after these initialisations */
 
-	/* the one exchange: every device's result table holds its own rows; an RCCL all-reduce (sum) completes them all */
-	for (int x = 0; x < n_dev; x++) {
-		if (!(tab[x] = calloc((size_t)n_units * RES_FIELDS, sizeof(double)))) { rc = MCHIP_ERR_ALLOC; goto DONE; }
-		for (int u = x; u < n_units; u += n_dev) {
-			double *row = tab[x] + (size_t)u * RES_FIELDS;
-			row[0] = res[u].logL; row[1] = res[u].converged; row[2] = res[u].n_iter; row[3] = res[u].time_stop;
-			row[4] = res[u].iter_stop; row[5] = res[u].pindex; row[6] = res[u].fatal; row[7] = res[u].seconds_run; row[8] = 1.0;
-		}
+	/* the one exchange: every device's result table holds the rows its workers fitted; an RCCL all-reduce (sum)
+	 * completes them all */
+	for (int g = 0; g < n_gpus; g++)
+		if (!(tab[g] = calloc((size_t)n_units * RES_FIELDS, sizeof(double)))) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+	for (int u = 0; u < n_units; u++) {
+		double *row = tab[(u % n_dev) % n_gpus] + (size_t)u * RES_FIELDS;
+		row[0] = res[u].logL; row[1] = res[u].converged; row[2] = res[u].n_iter; row[3] = res[u].time_stop;
+		row[4] = res[u].iter_stop; row[5] = res[u].pindex; row[6] = res[u].fatal; row[7] = res[u].seconds_run; row[8] = 1.0;
 	}
-	if ((rc = get_comm(o, st, &comm))) goto DONE;
-	if ((rc = mchip_comm_all_reduce(comm, tab, n_units * RES_FIELDS, 0))) { fprintf(stderr, "ERROR [mc_main.c]: %s\n", mchip_comm_last_error(comm)); goto DONE; }
-	for (int x = 1; x < n_dev; x++)
+	if (exchange_needed(o)) {
+		if ((rc = get_comm(o, st, &comm))) goto DONE;
+		if ((rc = mchip_comm_all_reduce(comm, tab, n_units * RES_FIELDS, 0))) { fprintf(stderr, "ERROR [mc_main.c]: %s\n", mchip_comm_last_error(comm)); goto DONE; }
+	}
+	for (int x = 1; x < n_gpus; x++)
 		if (memcmp(tab[0], tab[x], sizeof(double) * (size_t)n_units * RES_FIELDS)) { fprintf(stderr, "ERROR [mc_main.c]: devices disagree after the all-reduce\n"); rc = MCHIP_ERR_STATE; goto DONE; }
 
 	/* replay the serial bookkeeping in unit order (multiclust.c:534-560, 618-627) */
@@ -439,8 +453,8 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 	}
 DONE:
 	if (w) for (int x = 0; x < n_dev; x++) { free(w[x].q); free(w[x].p); free(w[x].sik); }
-	if (tab) for (int x = 0; x < n_dev; x++) free(tab[x]);
-	free(w); free(th); free(res); free(tab); free(devs); free(count_K);
+	if (tab) for (int x = 0; x < n_gpus; x++) free(tab[x]);
+	free(w); free(th); free(res); free(tab); free(count_K);
 	return rc;
 }
 
@@ -449,7 +463,7 @@ static int shardable(const mc_cli_options *o)
 	/* MC_FORCE_SHARDED=1 sends even --gpus 1 through the sharded path (threads, jump-ahead, RCCL exchange, replay): the
 	 * single-GPU rehearsal used by tests/test_gpu_cli.py */
 	const int force = getenv("MC_FORCE_SHARDED") != NULL;
-	return (o->n_gpus > 1 || (force && o->n_gpus == 1)) && o->em.admixture && !o->target_revisit && !o->target_ll && !o->em.n_seconds;
+	return (o->n_gpus > 1 || o->n_streams > 1 || (force && o->n_gpus == 1)) && o->em.admixture && !o->target_revisit && !o->target_ll && !o->em.n_seconds;
 }
 
 /* estimate_model (multiclust.c:365-452): K = min_K..max_K, or H0 / HA when bootstrapping */
@@ -517,8 +531,9 @@ static void *bs_main(void *arg)
 {
 	bs_worker *w = arg;
 	mc_cli_options ow = *w->o;
-	ow.device = w->o->device + w->index;
-	ow.n_gpus = 0;			/* the fits of a replicate stay on this device */
+	ow.device = worker_device(w->o, w->index);
+	ow.n_gpus = 0;			/* the fits of a replicate stay on this device, on this worker's stream */
+	ow.n_streams = 1;
 	for (int b = w->index; b < w->o->n_bootstrap; b += w->n_dev) {
 		run_state ls = *w->st;
 		mc_simulation gen;
@@ -538,34 +553,38 @@ static void *bs_main(void *arg)
 
 static int run_bootstrap_sharded(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, run_state *st, int *ntime_out)
 {
-	const int n_dev = o->n_gpus < 1 ? 1 : o->n_gpus, B = o->n_bootstrap;
+	const int n_dev = n_workers(o), n_gpus = o->n_gpus < 1 ? 1 : o->n_gpus, B = o->n_bootstrap;
 	const uint64_t per_init = mc_draws_per_init(&o->em, md, st->alt_K);
 	const uint64_t units0 = st->null_K == 1 ? 1 : (uint64_t)o->n_init, units1 = (uint64_t)o->n_init;
 	bs_worker *w = calloc((size_t)n_dev, sizeof *w);
 	pthread_t *th = calloc((size_t)n_dev, sizeof *th);
-	double *ts = calloc((size_t)B, sizeof *ts), **tab = calloc((size_t)n_dev, sizeof *tab);
+	double *ts = calloc((size_t)B, sizeof *ts), **tab = calloc((size_t)n_gpus, sizeof *tab);
 	char **text = calloc((size_t)B, sizeof *text);
-	int *devs = calloc((size_t)n_dev, sizeof *devs), rc = 0, ntime = 0;
+	int rc = 0, ntime = 0;
 	mchip_comm *comm = NULL;
-	if (!w || !th || !ts || !tab || !text || !devs) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+	if (!w || !th || !ts || !tab || !text) { rc = MCHIP_ERR_ALLOC; goto DONE; }
 	for (int x = 0; x < n_dev; x++) {
 		w[x].o = o; w[x].d = d; w[x].md = md; w[x].st = st; w[x].index = x; w[x].n_dev = n_dev;
 		w[x].draws_per_replicate = mc_bootstrap_draws(&o->em, md) + (units0 + units1) * per_init;
 		w[x].ts = ts; w[x].text = text;
-		devs[x] = o->device + x;
 		if (pthread_create(&th[x], NULL, bs_main, &w[x])) { bs_main(&w[x]); th[x] = 0; }
 	}
 	for (int x = 0; x < n_dev; x++) if (th[x]) pthread_join(th[x], NULL);
 	for (int x = 0; x < n_dev; x++) if (w[x].rc) rc = w[x].rc;
 	if (rc) goto DONE;
 	mc_rng_jump(&st->rng, (uint64_t)B * w[0].draws_per_replicate);
-	/* the one exchange: rows (test statistic, fitted flag) of the replicates each device owns, summed over devices */
-	for (int x = 0; x < n_dev; x++) {
-		if (!(tab[x] = calloc((size_t)B * 2, sizeof(double)))) { rc = MCHIP_ERR_ALLOC; goto DONE; }
-		for (int b = x; b < B; b += n_dev) { tab[x][2 * b] = ts[b]; tab[x][2 * b + 1] = 1.0; }
+	/* the one exchange: rows (test statistic, fitted flag) of the replicates each device's workers own, summed over devices */
+	for (int g = 0; g < n_gpus; g++)
+		if (!(tab[g] = calloc((size_t)B * 2, sizeof(double)))) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+	for (int b = 0; b < B; b++) {
+		double *row = tab[(b % n_dev) % n_gpus] + 2 * (size_t)b;
+		row[0] = ts[b];
+		row[1] = 1.0;
 	}
-	if ((rc = get_comm(o, st, &comm))) goto DONE;
-	if ((rc = mchip_comm_all_reduce(comm, tab, B * 2, 0))) { fprintf(stderr, "ERROR [mc_main.c]: %s\n", mchip_comm_last_error(comm)); goto DONE; }
+	if (exchange_needed(o)) {
+		if ((rc = get_comm(o, st, &comm))) goto DONE;
+		if ((rc = mchip_comm_all_reduce(comm, tab, B * 2, 0))) { fprintf(stderr, "ERROR [mc_main.c]: %s\n", mchip_comm_last_error(comm)); goto DONE; }
+	}
 	for (int b = 0; b < B; b++) {
 		if (tab[0][2 * b + 1] != 1.0) { fprintf(stderr, "ERROR [mc_main.c]: bootstrap replicate %d was fitted %g times\n", b, tab[0][2 * b + 1]); rc = MCHIP_ERR_STATE; goto DONE; }
 		st->ts_bs = tab[0][2 * b];
@@ -575,9 +594,9 @@ static int run_bootstrap_sharded(const mc_cli_options *o, const mc_cli_data *d, 
 	}
 	*ntime_out = ntime;
 DONE:
-	if (tab) for (int x = 0; x < n_dev; x++) free(tab[x]);
+	if (tab) for (int x = 0; x < n_gpus; x++) free(tab[x]);
 	if (text) for (int b = 0; b < B; b++) free(text[b]);
-	free(w); free(th); free(ts); free(tab); free(text); free(devs);
+	free(w); free(th); free(ts); free(tab); free(text);
 	return rc;
 }
 
@@ -607,8 +626,8 @@ int main(int argc, const char **argv)
 	/* the reference seeds libc only when -r is given; otherwise rand() runs from glibc's default seed 1 although the
 	 * banner prints 1234567 */
 	mc_srand(&st.rng, o.seed_given ? o.em.seed : 1u);
-	if (o.n_gpus > 1 && !shardable(&o))
-		fprintf(stderr, "WARNING: --gpus applies to the admixture model with a fixed number of initialisations; running on one GPU\n");
+	if ((o.n_gpus > 1 || o.n_streams > 1) && !shardable(&o))
+		fprintf(stderr, "WARNING: --gpus / --streams apply to the admixture model with a fixed number of initialisations; running one fit at a time on one GPU\n");
 
 	if (o.n_repeat > 1 || o.repeat_seconds) {	/* timed_model_estimation (multiclust.c:201-347) */
 		const clock_t start = clock();
@@ -651,7 +670,7 @@ int main(int argc, const char **argv)
 		if ((!on_device && !sim) || !st.mle_q) { rc = MCHIP_ERR_ALLOC; goto END; }
 		/* whole replicates per device when there is at least one for each; otherwise (or on one device) the replicates run in
 		 * turn and --gpus shards the initialisations inside each */
-		const int by_replicate = on_device && shardable(&o) && o.n_bootstrap >= o.n_gpus;
+		const int by_replicate = on_device && shardable(&o) && o.n_bootstrap >= n_workers(&o);
 		if (by_replicate && (rc = run_bootstrap_sharded(&o, &d, &md, &st, &ntime))) goto END;
 		for (int b = 0; !by_replicate && b < o.n_bootstrap; b++) {
 			printf("Bootstrap dataset %d (of %d):", b + 1, o.n_bootstrap);

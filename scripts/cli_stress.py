@@ -42,4 +42,14 @@ for args, env in runs:
         sys.exit(1)
     tails.append([l for l in lines if "test statistics" in l or "p-value" in l])
 assert tails[2] == tails[3] == tails[4], (tails[2], tails[3], tails[4])
+# several fits at a time on one GPU: same summary line, less wall time on a data set this small
+finals = []
+for streams in (1, 4, 8):
+    t0 = time.time()
+    r = subprocess.run([binp, "-f", path, "-d", out, "-a", "-k", "3", "-n", "32", "-s", "3", "-r", "3", "--streams", str(streams)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    print("32 initialisations, --streams %d: wall %.1f s" % (streams, time.time() - t0), flush=True)
+    finals.append(r.stdout.strip().split("\n")[-1].split()[:12])
+assert finals[0] == finals[1] == finals[2], finals
 print("bootstrap: device, sharded and host-drawn runs print the same test statistics")

@@ -128,13 +128,14 @@ def test_cli_bootstrap_device_host_and_sharded_agree(tmp_path, monkeypatch):
     assert outs[0] == outs[2], outs
 
 
-@pytest.mark.parametrize("case", ["multi_admix_k4", "tetra_admix_k3"])
-def test_cli_sharded_path_on_one_gpu_reproduces_serial_reference(case, tmp_path, monkeypatch):
+@pytest.mark.parametrize("case,streams", [("multi_admix_k4", 1), ("tetra_admix_k3", 1), ("multi_admix_k4", 3)])
+def test_cli_sharded_path_on_one_gpu_reproduces_serial_reference(case, streams, tmp_path, monkeypatch):
     """The --gpus machinery (host thread per device, unit = initialisation, rand() jump-ahead, RCCL all-reduce of the
     result table, serial-order bookkeeping replay, winner's owner writes the files) rehearsed with one device:
     stdout and files must equal the reference's serial run."""
     monkeypatch.setenv("MC_FORCE_SHARDED", "1")
-    gdir, out = run_cli(case, tmp_path, extra=["--gpus", "1"])
+    # streams > 1: several workers (host thread + context + stream each) share the one GPU
+    gdir, out = run_cli(case, tmp_path, extra=["--gpus", "1", "--streams", str(streams)])
     ref_lines = CLOCK.sub("HH:MM:SS", open(os.path.join(gdir, "stdout.txt")).read()).strip().split("\n")
     got_lines = out.strip().split("\n")
     assert len(ref_lines) == len(got_lines), out
