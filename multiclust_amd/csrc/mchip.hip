@@ -633,6 +633,10 @@ static mchip_pass_args pass_args(mchip_context *ctx, int slot)
 	return a;
 }
 
+/* the "bad input" word of the layout kernels: the last double of d_scalars (slots 0..47 are in use), so that an
+ * initialisation allocates and frees nothing (hipFree waits for the whole device, i.e. for every other stream's fits) */
+static int *bad_flag(mchip_context *ctx) { return reinterpret_cast<int *>(ctx->d_scalars + 63); }
+
 /* ------------------------------------------------------------------ C-ABI */
 extern "C" {
 
@@ -762,12 +766,11 @@ static int set_shape(mchip_context *ctx, int I, int L, int ploidy, const int32_t
 static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
 {
 	const int I = ctx->I, L = ctx->L, ploidy = ctx->ploidy, T = ctx->T;
-	scoped_dev<int> d_bad;
-	HIPCHK(d_bad.alloc(1));
+	int *d_bad = bad_flag(ctx);
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
 	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_raw, I, L, ploidy, ctx->d_ua, 0,
-			   ctx->d_gtA, ctx->d_gtS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad.p);
+			   ctx->d_gtA, ctx->d_gtS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -820,16 +823,15 @@ int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
 	if (!geno) return MCHIP_OK;
 	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
 	scoped_dev<uint8_t> d_obs;
-	scoped_dev<int> d_bad;
+	int *d_bad = bad_flag(ctx);
 	HIPCHK(d_obs.alloc(n));
-	HIPCHK(d_bad.alloc(1));
 	HIPCHK(hipMalloc((void **)&ctx->d_initA, ctx->geno_bytes_A));
 	HIPCHK(hipMalloc((void **)&ctx->d_initS, ctx->geno_bytes_S));
 	HIPCHK(hipMemcpyAsync(d_obs, geno, n, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
 	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_obs.p, ctx->I, ctx->L, ctx->ploidy, ctx->d_ua, 0,
-			   ctx->d_initA, ctx->d_initS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad.p);
+			   ctx->d_initA, ctx->d_initS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1232,12 +1234,11 @@ static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to)
 	int rc;
 	if (!ctx->d_asA) HIPCHK(hipMalloc((void **)&ctx->d_asA, ctx->geno_bytes_A));
 	if (!ctx->d_asS) HIPCHK(hipMalloc((void **)&ctx->d_asS, ctx->geno_bytes_S));
-	scoped_dev<int> d_bad;
-	HIPCHK(d_bad.alloc(1));
+	int *d_bad = bad_flag(ctx);
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
 	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_raw, ctx->I, ctx->L, ctx->ploidy,
-			   (const int32_t *)nullptr, ctx->K, ctx->d_asA, ctx->d_asS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad.p);
+			   (const int32_t *)nullptr, ctx->K, ctx->d_asA, ctx->d_asS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
