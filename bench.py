@@ -246,16 +246,20 @@ def main():
         hlib.mchip_synchronize(ctx)
 
     def run_steps(n):
-        """n steps of the hot path as the host driver runs them: SQUAREM cycles one by one (each needs its log
-        likelihoods on the host), plain EM as ONE batch whose stopping rule runs on the device (mc_em's own path)."""
-        if accel:
+        """n steps of the hot path as the host driver (mc_em) runs them: ONE batch whose stopping rule -- and, for the
+        accelerated schemes, step size and accept test -- runs on the device."""
+        st = hip.RunState(logL=fit.mod.logL, abs_error=1e-300, n_iter=fit.mod.n_iter)
+        if accel and 1 <= accel <= 4:
+            # one batch of cycles decided on the device (mc_em's own path for -s 1..4)
+            rc = hlib.mchip_accel_run(ctx, fit.mod.pindex, accel, n, C.byref(st))
+        elif accel:
             for _ in range(n):
                 one_step()
             return
-        st = hip.RunState(logL=fit.mod.logL, abs_error=1e-300, n_iter=fit.mod.n_iter)
-        rc = hlib.mchip_em_run(ctx, 0, n, C.byref(st))
+        else:
+            rc = hlib.mchip_em_run(ctx, 0, n, C.byref(st))
         if rc or st.fatal or st.stopped:
-            raise SystemExit("mchip_em_run: rc=%d fatal=%d stopped=%d" % (rc, st.fatal, st.stopped))
+            raise SystemExit("batched run: rc=%d fatal=%d stopped=%d" % (rc, st.fatal, st.stopped))
         fit.mod.n_iter, fit.mod.logL = st.n_iter, st.logL
 
     barrier()

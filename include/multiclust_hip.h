@@ -127,6 +127,19 @@ typedef struct mchip_run_state {
 	int fatal;		/* 0, 1 = NaN log likelihood, 2 = log likelihood decrease (em_alg.c:106-120) */
 } mchip_run_state;
 int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *state);
+/*
+ * The same for the accelerated loop: n_cycles times accelerated_em_step (accel_em.c:35-114) as em() sequences it
+ * (em_alg.c:84-88) for one secant pair and no back-tracking -- scheme 1, 2, 3 = SQUAREM S1-S3, 4 = QN with q = 1
+ * (options::accel_scheme, multiclust.h:125-131) -- enqueued without a host round trip: em_2_steps with both stop() calls,
+ * log_likelihood of the second EM iterate, step_size, accelerated_update with its log_likelihood, accept iff ll > emll,
+ * all decided on the device.  `slot` holds the starting iterate (model::pindex) and, on return, the iterate the reference
+ * would report (its pindex: the accepted extrapolation, else the second EM iterate, else -- when the stopping rule fired
+ * inside em_2_steps -- the cycle's starting iterate, accel_em.c:44-45); the other two slots are scratch.  Same arithmetic as
+ * driving the cycle call by call (mchip_em_step, mchip_secant, mchip_loglik, mchip_step_dots, mchip_accel_update,
+ * mchip_loglik_prefetch).  Admixture model with individual mixing proportions and n_secants >= 1; otherwise
+ * MCHIP_ERR_UNSUPPORTED.
+ */
+int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchip_run_state *state);
 
 /* E step only (em_e_step's trailing E step, em_alg.c:226,230): refreshes the expected counts, returns logL. */
 int mchip_e_step(mchip_context *ctx, int slot, double *loglik);

@@ -68,6 +68,8 @@ struct mchip_context {
 	double *h_pinned;		/* 64 doubles */
 	mchip_run_state *d_run;		/* batched-run state (mchip_em_run) */
 	hipGraphExec_t step_graph[3];	/* one captured {EM step + stop check} per slot; rebuilt when the model changes */
+	hipGraphExec_t cycle_graph[3][5];	/* one captured accelerated cycle per (start slot, scheme) */
+	int *d_cyc;			/* batched accelerated runs: [0] no update this cycle, [1] extrapolation accepted */
 	int have_ll;
 	int s_cache_slot;		/* slot whose S-side sums + logL are held in Spart / d_scalars[2] (mchip_loglik_prefetch), or -1 */
 	/* profiling */
@@ -432,10 +434,10 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_p(int L, int K, int T,
 
 /* projection of every (l,k) block of a P slot (accelerated updates, accel_em.c:474-475) */
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_project_p(int L, int K, const int32_t *__restrict__ toff, double *P,
-		double lb, uint8_t *flags)
+		double lb, uint8_t *flags, const int *stop = nullptr)
 {
 	const size_t idx = (size_t)blockIdx.x * MCHIP_BLOCK + threadIdx.x;
-	if (idx >= (size_t)L * K) return;
+	if (idx >= (size_t)L * K || (stop && *stop)) return;
 	const int k = (int)(idx % K);
 	const int l = (int)(idx / K);
 	const int c0 = toff[l], M = toff[l + 1] - c0;
@@ -511,18 +513,20 @@ __global__ void k_stop_check(mchip_run_state *s, const double *ll)
 }
 
 /* secant: out = x_to - x_from (em_alg.c:1104-1161) */
-__global__ void k_diff(const double *__restrict__ a, const double *__restrict__ b, double *out, size_t n)
+__global__ void k_diff(const double *__restrict__ a, const double *__restrict__ b, double *out, size_t n, const int *stop = nullptr)
 {
 	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (stop && *stop) return;
 	if (idx < n) out[idx] = a[idx] - b[idx];
 }
 
 /* three dot products of accel_em.c:143-184 (mode 0: utu, u(v-u), (v-u)^2) or the two of 291-310
  * (mode 1: u1.u2, u1.v2) over one array pair; block partials, combined by k_reduce_sum */
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_dots(const double *__restrict__ u, const double *__restrict__ v,
-		const double *__restrict__ u2, size_t n, int mode, double *part)
+		const double *__restrict__ u2, size_t n, int mode, double *part, const int *stop = nullptr)
 {
 	__shared__ double red[3][MCHIP_BLOCK];
+	if (stop && *stop) return;
 	double s0 = 0, s1 = 0, s2 = 0;
 	for (size_t x = (size_t)blockIdx.x * MCHIP_BLOCK + threadIdx.x; x < n; x += (size_t)gridDim.x * MCHIP_BLOCK) {
 		if (mode == 0) {
@@ -552,10 +556,11 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_dots(const double *__restrict__
 
 /* accel_em.c:444-541 element updates (projection follows in k_project_*) */
 __global__ void k_accel_update(const double *__restrict__ base, const double *__restrict__ u, const double *__restrict__ v,
-			       double *out, size_t n, double s, int qn_form)
+			       double *out, size_t n, double s, int qn_form, const double *s_dev = nullptr, const int *stop = nullptr)
 {
 	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= n) return;
+	if (idx >= n || (stop && *stop)) return;
+	if (s_dev) s = *s_dev;		/* batched accelerated runs: the step size was computed on the device */
 	if (qn_form) out[idx] = base[idx] + u[idx] + s * v[idx];
 	else out[idx] = base[idx] - 2 * s * u[idx] + s * s * (v[idx] - u[idx]);
 }
@@ -568,6 +573,41 @@ __global__ void k_add(const double *__restrict__ a, const double *__restrict__ b
 {
 	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (idx < n) out[idx] = a[idx] + b[idx];
+}
+
+/* step_size() of accel_em.c:130-243 on the device (batched accelerated runs): sc[16..18] / sc[20..22] are the eta / p
+ * parts of utu, u(v-u), (v-u)^2 (eta terms first, accel_em.c:143-184); the step goes to sc[24]; cyc[0] = 1 when the
+ * reference would leave the cycle without an update (NaN / infinite step, S3's sqrt(utu) < 1e-8 guard) */
+__global__ void k_step_size(double *sc, int scheme, int *cyc, const int *stop)
+{
+	if (threadIdx.x || blockIdx.x || (stop && *stop)) return;
+	const double utu = sc[16] + sc[20], utvu = sc[17] + sc[21], vutvu = sc[18] + sc[22];
+	double s;
+	if (scheme == 1) s = utu / utvu;
+	else if (scheme == 2) s = utvu / vutvu;
+	else if (scheme == 3) s = (sqrt(utu) < 1e-8) ? (double)NAN : -sqrt(utu / vutvu);
+	else s = -utu / utvu;				/* QN with one secant */
+	if (scheme < 4 && s > -1) s = -1;		/* SQUAREM clamp (accel_em.c:236-237); false for NaN */
+	sc[24] = s;
+	cyc[0] = (s != s || s - s != 0.0) ? 1 : 0;	/* isnan || isinf */
+}
+
+/* accept iff ll(extrapolated) > ll(second EM iterate) (accel_em.c:88); cyc[1] = accepted, which is also "the S-side sums of
+ * the next cycle's first E step are already in place" */
+__global__ void k_accept(const double *sc, int *cyc, const int *stop)
+{
+	if (threadIdx.x || blockIdx.x || (stop && *stop)) return;
+	cyc[1] = (!cyc[0] && sc[2] > sc[1]) ? 1 : 0;
+}
+
+/* the cycle's outcome goes back to the slot every cycle starts from: the extrapolated point if accepted, else the second
+ * EM iterate (pindex = tindex / findex, accel_em.c:89-101), so that the slot roles are the same in every cycle */
+__global__ void k_select_copy(double *dst, const double *__restrict__ if_accepted, const double *__restrict__ otherwise, size_t n,
+			      const int *cyc, const int *stop)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= n || (stop && *stop)) return;
+	dst[idx] = cyc[1] ? if_accepted[idx] : otherwise[idx];
 }
 
 /* ------------------------------------------------------------------ helpers */
@@ -597,6 +637,9 @@ static void free_model(mchip_context *ctx)
 {
 	for (int s = 0; s < 3; s++)
 		if (ctx->step_graph[s]) { (void)hipGraphExecDestroy(ctx->step_graph[s]); ctx->step_graph[s] = nullptr; }
+	for (int s = 0; s < 3; s++)
+		for (int m = 0; m < 5; m++)
+			if (ctx->cycle_graph[s][m]) { (void)hipGraphExecDestroy(ctx->cycle_graph[s][m]); ctx->cycle_graph[s][m] = nullptr; }
 	for (int s = 0; s < 3; s++) { dfree(ctx->d_p[s]); dfree(ctx->d_q[s]); }
 	for (int s = 0; s < MCHIP_MAX_SECANTS; s++) { dfree(ctx->d_up[s]); dfree(ctx->d_vp[s]); dfree(ctx->d_uq[s]); dfree(ctx->d_vq[s]); }
 	dfree(ctx->d_sik); dfree(ctx->d_stage); dfree(ctx->d_logp); dfree(ctx->d_ssum); dfree(ctx->d_Apart); dfree(ctx->d_Spart); dfree(ctx->d_llpart);
@@ -670,6 +713,7 @@ int mchip_create(mchip_context **out, int device)
 	if (hipHostMalloc((void **)&ctx->h_pinned, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
 	    hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(double)) != hipSuccess ||
 	    hipMalloc((void **)&ctx->d_run, sizeof(mchip_run_state)) != hipSuccess ||
+	    hipMalloc((void **)&ctx->d_cyc, 4 * sizeof(int)) != hipSuccess ||
 	    hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
 		delete ctx;
 		return MCHIP_ERR_ALLOC;
@@ -686,6 +730,7 @@ int mchip_destroy(mchip_context *ctx)
 	free_model(ctx);
 	free_data(ctx);
 	dfree(ctx->d_scalars);
+	dfree(ctx->d_cyc);
 	dfree(ctx->d_run);
 	if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
 	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -1042,7 +1087,7 @@ static int finalize_shared_eta(mchip_context *ctx, int to)
 {
 	hipLaunchKernelGGL(k_column_sums, dim3(ctx->K), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_sik, ctx->I, ctx->K, ctx->d_scalars + 8);
 	hipLaunchKernelGGL(k_normalize_row, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars + 8, ctx->K, ctx->d_q[to]);
-	if (ctx->do_projection) ctx->kt->project_q(1, ctx->K, ctx->d_q[to], ctx->eta_lb, ctx->stream);
+	if (ctx->do_projection) ctx->kt->project_q(1, ctx->K, ctx->d_q[to], ctx->eta_lb, nullptr, ctx->stream);
 	HIPCHK(hipGetLastError());
 	return MCHIP_OK;
 }
@@ -1078,11 +1123,12 @@ static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int m
 	return MCHIP_OK;
 }
 
-static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const int *stop = nullptr)
+static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const int *stop = nullptr, const int *skip_ind = nullptr)
 {
 	if (!ctx->admixture) return run_mixture(ctx, from, to, do_mstep, 0);
 	mchip_pass_args a = pass_args(ctx, from);
 	a.stop = stop;
+	a.skip_ind = skip_ind;
 	if (do_mstep || !ctx->sparse) {
 		prof_mark(ctx, MCHIP_KERN_ACCUM_P, true);
 		if (do_mstep) ctx->kt->accum_p(a, ctx->stream); else ctx->kt->loglik(a, ctx->stream);
@@ -1432,19 +1478,26 @@ int mchip_secant(mchip_context *ctx, int which, int j, int to, int from)
 	return MCHIP_OK;
 }
 
-static int dots_common(mchip_context *ctx, const double *uq, const double *vq, const double *u2q,
-		       const double *up, const double *vp, const double *u2p, int mode, int nout, double *out)
+/* the dot products' eta parts land in d_scalars[16 + x], the p parts in d_scalars[20 + x] */
+static void dots_enqueue(mchip_context *ctx, const double *uq, const double *vq, const double *u2q,
+			 const double *up, const double *vp, const double *u2p, int mode, int nout, const int *stop = nullptr)
 {
 	const size_t KT = (size_t)ctx->K * ctx->T;
 	const int gq = (int)((ctx->nq + 4095) / 4096) > 512 ? 512 : (int)((ctx->nq + 4095) / 4096);
 	const int gp = (int)((KT + 4095) / 4096) > 512 ? 512 : (int)((KT + 4095) / 4096);
 	double *part_q = ctx->d_redpart, *part_p = ctx->d_redpart + 3 * 512;
-	hipLaunchKernelGGL(k_dots, dim3(gq), dim3(MCHIP_BLOCK), 0, ctx->stream, uq, vq, u2q, (size_t)ctx->nq, mode, part_q);
-	hipLaunchKernelGGL(k_dots, dim3(gp), dim3(MCHIP_BLOCK), 0, ctx->stream, up, vp, u2p, KT, mode, part_p);
+	hipLaunchKernelGGL(k_dots, dim3(gq), dim3(MCHIP_BLOCK), 0, ctx->stream, uq, vq, u2q, (size_t)ctx->nq, mode, part_q, stop);
+	hipLaunchKernelGGL(k_dots, dim3(gp), dim3(MCHIP_BLOCK), 0, ctx->stream, up, vp, u2p, KT, mode, part_p, stop);
 	for (int x = 0; x < nout; x++) {
-		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, part_q + (size_t)x * gq, gq, ctx->d_scalars + 16 + x);
-		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, part_p + (size_t)x * gp, gp, ctx->d_scalars + 20 + x);
+		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, part_q + (size_t)x * gq, gq, ctx->d_scalars + 16 + x, stop);
+		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, part_p + (size_t)x * gp, gp, ctx->d_scalars + 20 + x, stop);
 	}
+}
+
+static int dots_common(mchip_context *ctx, const double *uq, const double *vq, const double *u2q,
+		       const double *up, const double *vp, const double *u2p, int mode, int nout, double *out)
+{
+	dots_enqueue(ctx, uq, vq, u2q, up, vp, u2p, mode, nout);
 	HIPCHK(hipGetLastError());
 	double tmp[8];
 	int rc = fetch_scalars(ctx, 16, 8, tmp);
@@ -1472,12 +1525,12 @@ int mchip_secant_dots(mchip_context *ctx, int j1, int j2, double *out2)
 	return dots_common(ctx, ctx->d_uq[j1], ctx->d_vq[j2], ctx->d_uq[j2], ctx->d_up[j1], ctx->d_vp[j2], ctx->d_up[j2], 1, 2, out2);
 }
 
-static int project_slot(mchip_context *ctx, int to)
+static int project_slot(mchip_context *ctx, int to, const int *stop = nullptr)
 {
 	if (!ctx->do_projection) return MCHIP_OK;
 	hipLaunchKernelGGL(k_project_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
-			   ctx->L, ctx->K, ctx->d_toff, ctx->d_p[to], ctx->p_lb, ctx->d_flags);
-	ctx->kt->project_q(ctx->qstride ? ctx->I : 1, ctx->K, ctx->d_q[to], ctx->eta_lb, ctx->stream);
+			   ctx->L, ctx->K, ctx->d_toff, ctx->d_p[to], ctx->p_lb, ctx->d_flags, stop);
+	ctx->kt->project_q(ctx->qstride ? ctx->I : 1, ctx->K, ctx->d_q[to], ctx->eta_lb, stop, ctx->stream);
 	HIPCHK(hipGetLastError());
 	return MCHIP_OK;
 }
@@ -1494,6 +1547,102 @@ int mchip_accel_update(mchip_context *ctx, int to, int base, int j, double s, in
 	hipLaunchKernelGGL(k_accel_update, dim3(nblk(ctx->nq)), dim3(256), 0, ctx->stream, ctx->d_q[base], ctx->d_uq[j], ctx->d_vq[j], ctx->d_q[to], (size_t)ctx->nq, s, qn_form);
 	HIPCHK(hipGetLastError());
 	return project_slot(ctx, to);
+}
+
+/* One accelerated cycle = accelerated_em_step (accel_em.c:35-114) with one secant pair and no back-tracking, enqueued
+ * without a host round trip: slot A holds the cycle's starting iterate, B = A+1 its first EM iterate and later the
+ * extrapolated point, C = A+2 the second EM iterate.  Every decision the reference takes on the host is taken by a
+ * one-thread kernel (stop rule twice, step size, accept test); the cycle's outcome is copied back to A so that the next
+ * cycle has the same slot roles, which is what lets one captured graph serve every cycle. */
+static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
+{
+	const int B = (A + 1) % 3, C = (A + 2) % 3;
+	const int *stop = &ctx->d_run->stopped;
+	int *cyc = ctx->d_cyc;
+	const size_t KT = (size_t)ctx->K * ctx->T, nq = (size_t)ctx->nq;
+	int rc;
+	/* em_2_steps (em_alg.c:1072-1211): E(A) M(->B) stop, u = B - A; E(B) M(->C) stop, v = C - B */
+	if ((rc = run_estep(ctx, A, B, 1, stop, cyc + 1))) return rc;
+	hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(64), 0, ctx->stream, ctx->d_run, ctx->d_scalars);
+	hipLaunchKernelGGL(k_diff, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[B], ctx->d_p[A], ctx->d_up[0], KT, stop);
+	hipLaunchKernelGGL(k_diff, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[B], ctx->d_q[A], ctx->d_uq[0], nq, stop);
+	if ((rc = run_estep(ctx, B, C, 1, stop, nullptr))) return rc;
+	hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(64), 0, ctx->stream, ctx->d_run, ctx->d_scalars);
+	hipLaunchKernelGGL(k_diff, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[C], ctx->d_p[B], ctx->d_vp[0], KT, stop);
+	hipLaunchKernelGGL(k_diff, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[C], ctx->d_q[B], ctx->d_vq[0], nq, stop);
+	/* emll = log_likelihood(findex = C) -> d_scalars[1] (accel_em.c:53) */
+	{
+		mchip_pass_args a = pass_args(ctx, C);
+		a.stop = stop;
+		prof_mark(ctx, MCHIP_KERN_LOGLIK, true);
+		ctx->kt->loglik(a, ctx->stream);
+		prof_mark(ctx, MCHIP_KERN_LOGLIK, false);
+		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_ll_ind, ctx->d_scalars + 1, stop);
+	}
+	/* step size (accel_em.c:130-243) -> d_scalars[24] */
+	dots_enqueue(ctx, ctx->d_uq[0], ctx->d_vq[0], nullptr, ctx->d_up[0], ctx->d_vp[0], nullptr, 0, 3, stop);
+	hipLaunchKernelGGL(k_step_size, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars, scheme, cyc, stop);
+	/* accelerated_update (accel_em.c:422-551): B = A - 2 s u + s^2 (v - u) (or A + u + s v), projected; its log likelihood,
+	 * taken by the pass that also leaves the S-side sums -> d_scalars[2] */
+	hipLaunchKernelGGL(k_accel_update, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[A], ctx->d_up[0], ctx->d_vp[0], ctx->d_p[B], KT, 0.0, scheme == 4, ctx->d_scalars + 24, stop);
+	hipLaunchKernelGGL(k_accel_update, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[A], ctx->d_uq[0], ctx->d_vq[0], ctx->d_q[B], nq, 0.0, scheme == 4, ctx->d_scalars + 24, stop);
+	if ((rc = project_slot(ctx, B, stop))) return rc;
+	{
+		mchip_pass_args a = pass_args(ctx, B);
+		a.stop = stop;
+		prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
+		ctx->kt->accum_q(a, ctx->stream);
+		prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
+		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_ll_ind, ctx->d_scalars + 2, stop);
+	}
+	/* accept iff ll > emll; the outcome goes back to slot A */
+	hipLaunchKernelGGL(k_accept, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars, cyc, stop);
+	hipLaunchKernelGGL(k_select_copy, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[A], ctx->d_p[B], ctx->d_p[C], KT, cyc, stop);
+	hipLaunchKernelGGL(k_select_copy, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[A], ctx->d_q[B], ctx->d_q[C], nq, cyc, stop);
+	HIPCHK(hipGetLastError());
+	return MCHIP_OK;
+}
+
+int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchip_run_state *state)
+{
+	int rc = check_slot(ctx, slot);
+	if (rc) return rc;
+	if (!state || n_cycles < 1 || scheme < 1 || scheme > 4) return fail(ctx, MCHIP_ERR_INVALID, "accel_run: bad arguments%s", nullptr);
+	if (!ctx->admixture || !ctx->qstride || !ctx->sparse || ctx->nsec < 1)
+		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "accel_run: admixture model with individual mixing proportions, sparse path, one secant pair%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipMemcpyAsync(ctx->d_run, state, sizeof *state, hipMemcpyHostToDevice, ctx->stream));
+	/* does Spart hold the S-side sums of this very slot (mchip_loglik_prefetch, or the accepted cycle that ended the
+	 * previous call)?  The first E step of the batch is told through the device flag the later cycles set themselves */
+	const int cyc0[4] = { 0, ctx->s_cache_slot == slot ? 1 : 0, 0, 0 };
+	HIPCHK(hipMemcpyAsync(ctx->d_cyc, cyc0, sizeof cyc0, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));	/* cyc0 is a stack array */
+	ctx->s_cache_slot = -1;
+	bool use_graph = !ctx->profiling && !getenv("MCHIP_NO_GRAPH");
+	hipGraphExec_t &exec = ctx->cycle_graph[slot][scheme];
+	if (use_graph && !exec) {
+		hipGraph_t graph = nullptr;
+		if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+			rc = accel_cycle_enqueue(ctx, slot, scheme);
+			const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+			if (rc || e != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+			if (graph) (void)hipGraphDestroy(graph);
+			(void)hipGetLastError();
+		}
+		if (!exec) use_graph = false;
+	}
+	for (int c = 0; c < n_cycles; c++) {
+		if (use_graph) HIPCHK(hipGraphLaunch(exec, ctx->stream));
+		else if ((rc = accel_cycle_enqueue(ctx, slot, scheme))) return rc;
+	}
+	int cyc_out[4] = { 0, 0, 0, 0 };
+	HIPCHK(hipMemcpyAsync(state, ctx->d_run, sizeof *state, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipMemcpyAsync(cyc_out, ctx->d_cyc, sizeof cyc_out, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	/* a batch that ran to its end on an accepted cycle leaves that cycle's sums for whoever continues from this slot */
+	ctx->s_cache_slot = (!state->stopped && cyc_out[1]) ? slot : -1;
+	ctx->have_ll = 1;
+	return MCHIP_OK;
 }
 
 int mchip_multisecant_update(mchip_context *ctx, int to, int base, int u_index, int n_terms,

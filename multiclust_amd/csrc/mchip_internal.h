@@ -54,6 +54,9 @@ struct mchip_pass_args {
 	int tile_cols;		/* LDS tile capacity in allele columns (8 * max alleles per locus) */
 	/* batched runs: when non-null and *stop != 0 every kernel of the step returns at once */
 	const int *stop;
+	/* batched accelerated runs: when non-null and *skip_ind != 0 the S-side pass returns at once, because the pass that
+	 * took the log likelihood of these very parameters (the accepted extrapolation) already left its sums in Spart */
+	const int *skip_ind;
 	/* hard-partition first M step */
 	const uint8_t *asA, *asS;	/* assignment bytes in the gtA / gtS layouts */
 };
@@ -68,7 +71,7 @@ struct mchip_ktable {
 	/* finalize: Q[to] from Spart (normalise + project), stores expected counts */
 	void (*finalize_q)(int I, int K, int n_lchunks, const double *Spart, const double *Qfrom, int qstride_from,
 			   double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, const int *stop, hipStream_t s);
-	void (*project_q)(int nrows, int K, double *Q, double lb, hipStream_t s);
+	void (*project_q)(int nrows, int K, double *Q, double lb, const int *stop, hipStream_t s);
 	/* mixture model */
 	void (*mix_gather)(const mchip_pass_args &a, hipStream_t s);	/* a.P = log P table; Spart = per-chunk sums */
 	void (*mix_finalize)(int I, int n_lchunks, const double *Vpart, const double *eta, double *vik, double *llpart, int mode, hipStream_t s);

@@ -321,6 +321,7 @@ template <int PL>
 __global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
 {
 	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
+	if (a.skip_ind && *a.skip_ind) return;	/* sums of these parameters are already in Spart */
 	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
 	const bool active = i_raw < a.I;
 	const int i = active ? i_raw : a.I - 1;
@@ -403,6 +404,7 @@ template <int PL, bool ACCUM, bool SAFE, bool NOMISS>
 __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_sparse(mchip_pass_args a)
 {
 	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
+	if (ACCUM && a.skip_ind && *a.skip_ind) return;	/* sums + logL partials of these parameters are already there */
 	extern __shared__ __attribute__((aligned(16))) double lds[];	/* [2][tile_cols][KP] then [QBLOCK] reduction scratch */
 	double *red = lds + 2 * (size_t)a.tile_cols * KP;
 	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
@@ -856,10 +858,10 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_q(int I, int n_lchunks
 }
 
 /* projection of nrows rows of K (accelerated updates, accel_em.c:510-511; shared eta row) */
-__global__ __launch_bounds__(MCHIP_BLOCK) void k_project_q(int nrows, double *Q, double lb)
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_project_q(int nrows, double *Q, double lb, const int *stop)
 {
 	const int i = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
-	if (i >= nrows) return;
+	if (i >= nrows || (stop && *stop)) return;
 	double s[K];
 #pragma unroll
 	for (int k = 0; k < K; k++) s[k] = Q[(size_t)i * K + k];
@@ -956,9 +958,9 @@ void launch_finalize_q(int I, int, int n_lchunks, const double *Spart, const dou
 	hipLaunchKernelGGL(k_finalize_q, dim3((I + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s,
 			   I, n_lchunks, Spart, Qfrom, qstride_from, Qto, sik, do_mstep, weighted, do_projection, lb, stop);
 }
-void launch_project_q(int nrows, int, double *Q, double lb, hipStream_t s)
+void launch_project_q(int nrows, int, double *Q, double lb, const int *stop, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_project_q, dim3((nrows + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s, nrows, Q, lb);
+	hipLaunchKernelGGL(k_project_q, dim3((nrows + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s, nrows, Q, lb, stop);
 }
 
 }  // namespace

@@ -59,6 +59,7 @@ def load():
         "mchip_e_step": ([vp, i32, dp], i32),
         "mchip_loglik": ([vp, i32, dp], i32),
         "mchip_loglik_prefetch": ([vp, i32, dp], i32),
+        "mchip_accel_run": ([vp, i32, i32, i32, vp], i32),
         "mchip_mstep_from_partition": ([vp, vp, i32], i32),
         "mchip_mstep_from_rand_partition": ([vp, vp, i32], i32),
         "mchip_get_genotypes": ([vp, vp], i32),
@@ -89,7 +90,7 @@ def load():
 ABI_SYMBOLS = [
     "mchip_abi_version", "mchip_device_count", "mchip_create", "mchip_destroy", "mchip_last_error",
     "mchip_synchronize", "mchip_set_genotypes", "mchip_set_model", "mchip_set_p", "mchip_get_p", "mchip_set_q",
-    "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_em_run", "mchip_last_loglik", "mchip_e_step",
+    "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_em_run", "mchip_accel_run", "mchip_last_loglik", "mchip_e_step",
     "mchip_loglik", "mchip_loglik_prefetch", "mchip_mstep_from_partition", "mchip_mstep_from_rand_partition",
     "mchip_get_genotypes", "mchip_simulate_genotypes", "mchip_set_init_genotypes",
     "mchip_get_expected_counts", "mchip_secant", "mchip_step_dots",

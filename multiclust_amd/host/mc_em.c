@@ -662,6 +662,43 @@ static int em_batched(const mc_options *opt, mc_model *mod)
 	return 0;
 }
 
+/* The accelerated loop of em() (em_alg.c:84-88) in batches of cycles that run on the device without a host round trip
+ * (mchip_accel_run): one secant pair, no back-tracking, nothing printed per iteration, no wall-clock limit.  Returns -1
+ * when the device path does not cover the model (the caller then drives the cycles one by one). */
+#define MC_ACCEL_BATCH 8
+static int em_accel_batched(const mc_options *opt, mc_model *mod)
+{
+	const int scheme = opt->accel_scheme;		/* 1..3 SQUAREM, 4 = QN with q = 1 */
+	while (!mod->stopped) {
+		mchip_run_state st;
+		memset(&st, 0, sizeof st);
+		st.logL = mod->logL;
+		st.abs_error = opt->abs_error;
+		st.rel_error = opt->rel_error;
+		st.n_iter = mod->n_iter;
+		st.max_iter = opt->max_iter;
+		const int rc = mchip_accel_run(mod->dev, mod->pindex, scheme, MC_ACCEL_BATCH, &st);
+		if (rc == MCHIP_ERR_UNSUPPORTED) return -1;
+		if (dev_fail(mod, rc, "mc_em")) return 0;
+		mod->n_iter = st.n_iter;
+		mod->logL = st.logL;
+		mod->findex = mod->tindex = mod->pindex;	/* the reported iterate; the other two slots are scratch */
+		if (st.converged) mod->converged = 1;
+		if (st.iter_stop) mod->iter_stop = 1;
+		if (st.fatal == 1) {
+			fprintf(stderr, "ERROR [em_alg.c::stop(107)]: nan\n");
+			mod->fatal = MC_FATAL_NAN;
+		} else if (st.fatal == 2) {
+			fprintf(stderr, "ERROR [em_alg.c::stop(116)]: log likelihood decrease (%f < %f; %e)\n",
+				st.bad_loglik, st.logL, (st.bad_loglik - st.logL) / st.bad_loglik);
+			mod->fatal = MC_FATAL_DECREASE;
+		}
+		if (st.stopped) mod->stopped = 1;
+	}
+	mod->seconds_run = ((double)clock() - mod->start) / CLOCKS_PER_SEC;
+	return 0;
+}
+
 void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod)
 {
 	/* em_alg.c:44-90 */
@@ -681,6 +718,10 @@ void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod)
 		mod->pindex = mod->findex;
 	}
 	if (mod->converged || mod->fatal) return;
+	if (opt->accel_scheme >= MC_SQS1 && opt->accel_scheme <= MC_QN && opt->q == 1 && !opt->adjust_step && !stop &&
+	    opt->admixture && !opt->eta_constrained && opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
+	    !getenv("MC_NO_BATCH") && em_accel_batched(opt, mod) == 0)
+		return;
 	do {
 		if (!opt->accel_scheme)
 			stop = mc_em_step(opt, dat, mod);

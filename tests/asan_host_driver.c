@@ -22,6 +22,7 @@ int mchip_get_genotypes(mchip_context*c,uint8_t*g){(void)c;(void)g;return 2;}
 int mchip_simulate_genotypes(mchip_context*c,int I,int L,int p,const int32_t*u,const uint32_t*w,int K,int e,const double*q,const double*pp){(void)c;(void)I;(void)L;(void)p;(void)u;(void)w;(void)K;(void)e;(void)q;(void)pp;return 2;}
 int mchip_em_step(mchip_context*c,int a,int b,double*l){(void)c;(void)a;(void)b;(void)l;return 2;}
 int mchip_em_run(mchip_context*c,int a,int b,mchip_run_state*l){(void)c;(void)a;(void)b;(void)l;return 2;}
+int mchip_accel_run(mchip_context*c,int a,int s,int b,mchip_run_state*l){(void)c;(void)a;(void)s;(void)b;(void)l;return 2;}
 int mchip_e_step(mchip_context*c,int a,double*l){(void)c;(void)a;(void)l;return 2;}
 int mchip_loglik(mchip_context*c,int a,double*l){(void)c;(void)a;(void)l;return 2;}
 int mchip_loglik_prefetch(mchip_context*c,int a,double*l){(void)c;(void)a;(void)l;return 2;}

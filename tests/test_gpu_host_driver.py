@@ -217,3 +217,51 @@ def test_batched_em_iteration_cap_and_decrease_detection():
     fit.lib.mc_em(*fit._a())
     assert fit.mod.fatal == 2 and fit.mod.n_iter == 1  # the reference would exit(0) here (em_alg.c:115-120)
     fit.close()
+
+
+@pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "multi_admix_k4_s1", "multi_admix_k4_s2",
+                                  "multi_admix_k3_qn1", "tetra_admix_k3", "missing_admix_k3"])
+def test_batched_accelerated_run_equals_cycle_by_cycle(name, monkeypatch):
+    """mc_em with an acceleration scheme runs its cycles in device-side batches (mchip_accel_run: stop rule, step size and
+    accept test decided by one-thread kernels, one captured graph per cycle).  Same arithmetic as the cycle-by-cycle host
+    loop: iteration count, flags, log likelihood and the reported iterate are identical bit for bit."""
+    g = Golden(name)
+    out = []
+    for batched in (True, False):
+        if batched:
+            monkeypatch.delenv("MC_NO_BATCH", raising=False)
+        else:
+            monkeypatch.setenv("MC_NO_BATCH", "1")
+        fit = make_fit(g, accel=g.m["accel_scheme"])
+        fit.em()
+        m = fit.mod
+        assert m.fatal == 0
+        out.append((m.n_iter, m.converged, m.iter_stop, m.logL, fit.get_q(m.pindex), fit.get_p(m.pindex), fit.expected_counts()))
+        fit.close()
+    a, b = out
+    assert a[:4] == b[:4], (a[:4], b[:4])
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    assert np.array_equal(a[6], b[6])
+
+
+def test_batched_accelerated_run_honours_the_iteration_cap():
+    """-T n with -s 3: stop() counts EM steps, so the cap can fire inside em_2_steps; the reported iterate is then the
+    cycle's starting point (accel_em.c:44-45)."""
+    g = Golden("multi_admix_k4")
+    res = []
+    for env in ({}, {"MC_NO_BATCH": "1"}):
+        import os
+        old = os.environ.pop("MC_NO_BATCH", None)
+        os.environ.update(env)
+        try:
+            fit = make_fit(g, accel=3, max_iter=6)
+            fit.em()
+            m = fit.mod
+            res.append((m.n_iter, m.iter_stop, m.converged, m.logL, fit.get_p(m.pindex)))
+            fit.close()
+        finally:
+            os.environ.pop("MC_NO_BATCH", None)
+            if old is not None:
+                os.environ["MC_NO_BATCH"] = old
+    assert res[0][:4] == res[1][:4] and res[0][0] == 7 and res[0][1] == 1
+    assert np.array_equal(res[0][4], res[1][4])
