@@ -296,7 +296,7 @@ def main():
         # HBM traffic per launch of the dominant kernel: PMC FETCH_SIZE/WRITE_SIZE from separate `rocprofv3 --pmc` passes
         # of this same command (scripts/summarize_profile.py; corrected as MI355X_MICROARCH.md prescribes), config 3 only
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_v4_c3_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r01_v5_c3_traffic.json")
         if args.workload == "c3" and os.path.exists(tf):
             want = "k_column_counts<2, false>" if dom == 0 else "k_individual_sparse<2, true, false, true>"
             traffic = json.load(open(tf)).get(want, {}).get("hbm_bytes_per_launch_corrected")

@@ -1689,12 +1689,20 @@ int mchip_profile_end(mchip_context *ctx, double *total_ms, double *kernel_ms, i
 	float ms = 0;
 	HIPCHK(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
 	if (total_ms) *total_ms = ms;
-	double km[MCHIP_KERN_COUNT] = {0, 0, 0};
+	double km[MCHIP_KERN_COUNT] = {0, 0, 0}, longest[MCHIP_KERN_COUNT] = {0, 0, 0};
 	int kl[MCHIP_KERN_COUNT] = {0, 0, 0};
+	std::vector<float> each(ctx->ev_kind.size(), 0.0f);
 	for (size_t p = 0; 2 * p + 1 < ctx->ev_used && p < ctx->ev_kind.size(); p++) {
-		HIPCHK(hipEventElapsedTime(&ms, ctx->ev_pool[2 * p], ctx->ev_pool[2 * p + 1]));
-		km[ctx->ev_kind[p]] += ms;
-		kl[ctx->ev_kind[p]]++;
+		HIPCHK(hipEventElapsedTime(&each[p], ctx->ev_pool[2 * p], ctx->ev_pool[2 * p + 1]));
+		if (each[p] > longest[ctx->ev_kind[p]]) longest[ctx->ev_kind[p]] = each[p];
+	}
+	/* a launch that returned at once (the S-side pass of a batched accelerated cycle whose sums were already in place, any
+	 * kernel after the stopping rule fired) did no pass over the data: it is not a launch of that kernel for these figures */
+	for (size_t p = 0; 2 * p + 1 < ctx->ev_used && p < ctx->ev_kind.size(); p++) {
+		const int kind = ctx->ev_kind[p];
+		if (each[p] < 0.05 * longest[kind]) continue;
+		km[kind] += each[p];
+		kl[kind]++;
 	}
 	for (int x = 0; x < MCHIP_KERN_COUNT; x++) {
 		if (kernel_ms) kernel_ms[x] = km[x];

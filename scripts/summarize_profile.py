@@ -40,6 +40,21 @@ def main():
                                                        float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6,
                                                        float(r["MaxNs"]) / 1e6, float(r["TotalDurationNs"]) / tot))
     print("wrote", out)
+    # launches that did a pass over the data: batched runs leave no-op launches behind (kernels that return at once after
+    # the stopping rule fired, or because their sums were already in place); per-dispatch durations tell them apart
+    tr = glob.glob(os.path.join(stats_dir, "**", "*_kernel_trace.csv"), recursive=True)
+    if tr:
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(tr[0])):
+            if ours(r["Kernel_Name"]):
+                dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        out2 = os.path.join(ROOT, "profiles", tag + "_kernel_stats_working_launches.csv")
+        with open(out2, "w") as g:
+            g.write("kernel,launches,working_launches,avg_ms_of_working_launches\n")
+            for k in sorted(dur, key=lambda k: -sum(dur[k])):
+                big = [d for d in dur[k] if d >= 0.05 * max(dur[k])]
+                g.write("%s,%d,%d,%.4f\n" % (k, len(dur[k]), len(big), sum(big) / len(big)))
+        print("wrote", out2)
     if len(sys.argv) >= 5:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for d in sys.argv[3:5]:
