@@ -64,6 +64,10 @@ def main():
                         agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         res = {}
         for k, c in agg.items():
+            # launches that return at once (see above) move no data: keep the dispatches above 5 % of the kernel's largest
+            for name in ("FETCH_SIZE", "WRITE_SIZE"):
+                if c.get(name):
+                    c[name] = [v for v in c[name] if v >= 0.05 * max(c[name])]
             fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) if c.get("FETCH_SIZE") else None
             write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) if c.get("WRITE_SIZE") else None
             res[k] = {
