@@ -1,0 +1,89 @@
+"""-m gpu: seeded random shapes through the C-ABI against the CPU oracle (fused order): sizes around the tile and block
+edges (8, 64, 128, 256), every ploidy 1..6, K 1..12, 2..7 alleles, with and without missing data, both eta forms, plain EM
+and one SQUAREM-3 cycle's log likelihoods."""
+import numpy as np
+import pytest
+
+import multiclust_amd as mc
+import oracle_bind as ob
+from synth import make_dataset, random_params
+
+pytestmark = pytest.mark.gpu
+
+
+def cases(n, seed):
+    rs = np.random.default_rng(seed)
+    edges = [1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 513, 1025]
+    out = []
+    for _ in range(n):
+        I = int(rs.choice(edges[3:]))
+        L = int(rs.choice(edges[3:]))
+        out.append((I, L, int(rs.integers(1, 13)), int(rs.integers(1, 7)), int(rs.integers(2, 8)),
+                    float(rs.choice([0.0, 0.0, 0.03, 0.2])), int(rs.integers(0, 2)), int(rs.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = mc.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,constrained,seed", cases(120, 20250117))
+def test_random_shapes_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, constrained, seed):
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=seed, missing=missing)
+    lb = ob.lib.mco_lower_bound(1e-8, I, ploidy)
+    q0, p0 = random_params(I, ua, K, seed=seed + 1, lower_bound=lb)
+    if constrained:
+        q0 = q0[0].copy()
+    opt = ob.make_options(lower_bound=lb, fused=1, abs_error=0.0, eta_constrained=constrained)
+    mod = ob.Model(ob.Data(I, L, ploidy, ua, geno), opt, K)
+    mod.q(0)[...] = q0
+    mod.p(0)[...] = p0
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, eta_constrained=constrained, lower_bound=lb)
+    ctx.set_q(0, q0)
+    ctx.set_p(0, p0)
+    for s in (1, 2):
+        mod.em_step()
+        ll = ctx.em_step(0, 0)
+        assert abs(ll - mod.logL) <= max(1e-8, 1e-12 * abs(mod.logL)), (s, ll, mod.logL)
+        rtol = 1e-11 if s == 1 else 1e-9
+        np.testing.assert_allclose(ctx.get_q(0), mod.q(0), rtol=rtol, atol=1e-15)
+        np.testing.assert_allclose(ctx.get_p(0), mod.p(0), rtol=rtol, atol=1e-15)
+        np.testing.assert_allclose(ctx.expected_counts(), mod.sik(), rtol=rtol, atol=1e-12)
+    ll_o = mod.loglik(0)
+    assert abs(ctx.loglik(0) - ll_o) <= max(1e-8, 1e-12 * abs(ll_o))
+    assert ctx.loglik_prefetch(0) == ctx.loglik(0)
+
+
+def mixture_cases(n, seed):
+    rs = np.random.default_rng(seed)
+    sizes = [9, 17, 64, 65, 129, 257, 300]
+    return [(int(rs.choice(sizes)), int(rs.choice(sizes)), int(rs.integers(1, 9)), int(rs.integers(1, 5)), int(rs.integers(2, 7)),
+             float(rs.choice([0.0, 0.03])), int(rs.integers(0, 1 << 30))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,seed", mixture_cases(24, 7))
+def test_random_shapes_mixture_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, seed):
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=seed, missing=missing)
+    lb = ob.lib.mco_lower_bound(1e-8, I, ploidy)
+    _, p0 = random_params(I, ua, K, seed=seed + 1, lower_bound=lb)
+    eta0 = np.full(K, 1.0 / K)
+    opt = ob.make_options(admixture=0, lower_bound=lb, abs_error=0.0)
+    mod = ob.Model(ob.Data(I, L, ploidy, ua, geno), opt, K)
+    mod.q(0)[...] = eta0
+    mod.p(0)[...] = p0
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, admixture=0, lower_bound=lb)
+    ctx.set_q(0, eta0)
+    ctx.set_p(0, p0)
+    for s in (1, 2):
+        mod.em_step()
+        ll = ctx.em_step(0, 0)
+        assert abs(ll - mod.logL) <= max(1e-8, 1e-12 * abs(mod.logL)), (s, ll, mod.logL)
+        np.testing.assert_allclose(ctx.get_q(0), mod.q(0), rtol=1e-7, atol=1e-13)
+        np.testing.assert_allclose(ctx.get_p(0), mod.p(0), rtol=1e-7, atol=1e-13)
+        np.testing.assert_allclose(ctx.expected_counts(), mod.sik(), rtol=1e-7, atol=1e-12)
+    assert abs(ctx.loglik(0) - mod.loglik(0)) <= max(1e-8, 1e-12 * abs(mod.logL))
