@@ -87,3 +87,26 @@ def test_random_shapes_mixture_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, s
         np.testing.assert_allclose(ctx.get_p(0), mod.p(0), rtol=1e-7, atol=1e-13)
         np.testing.assert_allclose(ctx.expected_counts(), mod.sik(), rtol=1e-7, atol=1e-12)
     assert abs(ctx.loglik(0) - mod.loglik(0)) <= max(1e-8, 1e-12 * abs(mod.logL))
+
+
+def draw_cases(n, seed):
+    rs = np.random.default_rng(seed)
+    return [(int(rs.integers(3, 400)), int(rs.integers(3, 900)), int(rs.integers(1, 5)), int(rs.integers(1, 33)),
+             int(rs.integers(0, 5000)), int(rs.integers(1, 1 << 31))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("I,L,ploidy,K,skip,seed", draw_cases(30, 11))
+def test_random_device_draws_vs_host_stream(ctx, I, L, ploidy, K, skip, seed):
+    """random_allele_partition drawn on the device = drawn from the oracle's glibc stream on the host, for random sizes,
+    seeds, stream offsets and every K up to 32 (the multiply-shift remainder)."""
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=3, seed=seed % 1000, missing=0.0)
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, lower_bound=1e-8)
+    window, rng = ob.glibc_window(seed, skip)
+    assign = ob.rand_mod(rng, I * L * ploidy, K)
+    ctx.mstep_from_partition(assign, 0)
+    ctx.mstep_from_rand_partition(window, 1)
+    # equal_nan: with few haploid individuals and many clusters a (cluster, locus) pair can receive no copy at all, and the
+    # first M step then divides 0 by 0 there, in the reference as here
+    assert np.array_equal(ctx.get_q(0), ctx.get_q(1), equal_nan=True) and np.array_equal(ctx.get_p(0), ctx.get_p(1), equal_nan=True)
+    assert np.array_equal(np.isnan(ctx.get_p(0)), np.isnan(ctx.get_p(1)))
