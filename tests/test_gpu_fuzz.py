@@ -110,3 +110,33 @@ def test_random_device_draws_vs_host_stream(ctx, I, L, ploidy, K, skip, seed):
     # first M step then divides 0 by 0 there, in the reference as here
     assert np.array_equal(ctx.get_q(0), ctx.get_q(1), equal_nan=True) and np.array_equal(ctx.get_p(0), ctx.get_p(1), equal_nan=True)
     assert np.array_equal(np.isnan(ctx.get_p(0)), np.isnan(ctx.get_p(1)))
+
+
+def accel_cases(n, seed):
+    rs = np.random.default_rng(seed)
+    return [(int(rs.integers(40, 200)), int(rs.integers(60, 400)), int(rs.integers(2, 6)), int(rs.choice([1, 2, 2, 2, 4])),
+             int(rs.integers(1, 5)), float(rs.choice([0.0, 0.02])), int(rs.choice([0, 0, 7, 30])), int(rs.integers(1, 1 << 20)))
+            for _ in range(n)]
+
+
+@pytest.mark.parametrize("I,L,K,ploidy,scheme,missing,max_iter,seed", accel_cases(16, 5))
+def test_random_accelerated_fits_batched_vs_cycle_by_cycle(I, L, K, ploidy, scheme, missing, max_iter, seed, monkeypatch):
+    """Whole accelerated fits (-s 1..4) from the same random initialisation: device-side batches of cycles against the
+    cycle-by-cycle host loop, bit for bit, with and without an iteration cap that can fire inside a cycle."""
+    from multiclust_amd import host
+    ua, geno = make_dataset(I, L, K, ploidy=ploidy, max_alleles=4, seed=seed, missing=missing)
+    out = []
+    for batched in (True, False):
+        if batched:
+            monkeypatch.delenv("MC_NO_BATCH", raising=False)
+        else:
+            monkeypatch.setenv("MC_NO_BATCH", "1")
+        fit = host.Fit(ua, geno, K, admixture=1, accel_scheme=scheme, verbosity=1, max_iter=max_iter)
+        fit.initialize(seed)
+        fit.em()
+        m = fit.mod
+        out.append((m.n_iter, m.converged, m.iter_stop, m.fatal, m.logL, fit.get_q(m.pindex), fit.get_p(m.pindex)))
+        fit.close()
+    a, b = out
+    assert a[:5] == b[:5], (a[:5], b[:5])
+    assert np.array_equal(a[5], b[5], equal_nan=True) and np.array_equal(a[6], b[6], equal_nan=True)
