@@ -114,8 +114,8 @@ int mchip_last_loglik(mchip_context *ctx, double *loglik);
  * enqueued without a host round trip per iteration; once the rule fires (convergence, iteration cap, NaN, decrease) the
  * remaining steps of the batch are no-ops, so parameters, n_iter and logL are those of the stopping iteration.
  * `state` is in/out: the host seeds it with model::logL / n_iter and reads back where the loop stands.
- * Available for the admixture model with individual mixing proportions; otherwise MCHIP_ERR_UNSUPPORTED (the caller
- * then iterates mchip_em_step).
+ * Available for the admixture model (individual or shared mixing proportions); otherwise MCHIP_ERR_UNSUPPORTED (the
+ * caller then iterates mchip_em_step).
  */
 typedef struct mchip_run_state {
 	double logL;		/* model::logL: log likelihood of the previous iteration (in), of the last executed one (out) */
@@ -136,8 +136,7 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
  * would report (its pindex: the accepted extrapolation, else the second EM iterate, else -- when the stopping rule fired
  * inside em_2_steps -- the cycle's starting iterate, accel_em.c:44-45); the other two slots are scratch.  Same arithmetic as
  * driving the cycle call by call (mchip_em_step, mchip_secant, mchip_loglik, mchip_step_dots, mchip_accel_update,
- * mchip_loglik_prefetch).  Admixture model with individual mixing proportions and n_secants >= 1; otherwise
- * MCHIP_ERR_UNSUPPORTED.
+ * mchip_loglik_prefetch).  Admixture model with n_secants >= 1; otherwise MCHIP_ERR_UNSUPPORTED.
  */
 int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchip_run_state *state);
 

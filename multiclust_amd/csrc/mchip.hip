@@ -445,9 +445,10 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_project_p(int L, int K, const i
 }
 
 /* shared eta (eta_constrained): eta_k = sum_i S_ik / sum, project (em_alg.c:604-648): one block per k */
-__global__ __launch_bounds__(MCHIP_BLOCK) void k_column_sums(const double *__restrict__ sik, int I, int K, double *out)
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_column_sums(const double *__restrict__ sik, int I, int K, double *out, const int *stop = nullptr)
 {
 	__shared__ double red[MCHIP_BLOCK];
+	if (stop && *stop) return;
 	const int k = blockIdx.x;
 	double s = 0.0;
 	for (int i = threadIdx.x; i < I; i += MCHIP_BLOCK) s += sik[(size_t)i * K + k];
@@ -459,9 +460,9 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_sums(const double *__res
 	}
 	if (threadIdx.x == 0) out[k] = red[0];
 }
-__global__ void k_normalize_row(const double *__restrict__ sums, int K, double *eta)
+__global__ void k_normalize_row(const double *__restrict__ sums, int K, double *eta, const int *stop = nullptr)
 {
-	if (threadIdx.x || blockIdx.x) return;
+	if (threadIdx.x || blockIdx.x || (stop && *stop)) return;
 	double temp = 0.0;
 	for (int k = 0; k < K; k++) temp += sums[k];
 	for (int k = 0; k < K; k++) eta[k] = sums[k] / temp;
@@ -1083,11 +1084,11 @@ static int fetch_scalars(mchip_context *ctx, int first, int count, double *out)
 }
 
 /* shared eta: eta[to] = normalise(sum_i S_ik), project (em_alg.c:604-648) */
-static int finalize_shared_eta(mchip_context *ctx, int to)
+static int finalize_shared_eta(mchip_context *ctx, int to, const int *stop = nullptr)
 {
-	hipLaunchKernelGGL(k_column_sums, dim3(ctx->K), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_sik, ctx->I, ctx->K, ctx->d_scalars + 8);
-	hipLaunchKernelGGL(k_normalize_row, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars + 8, ctx->K, ctx->d_q[to]);
-	if (ctx->do_projection) ctx->kt->project_q(1, ctx->K, ctx->d_q[to], ctx->eta_lb, nullptr, ctx->stream);
+	hipLaunchKernelGGL(k_column_sums, dim3(ctx->K), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_sik, ctx->I, ctx->K, ctx->d_scalars + 8, stop);
+	hipLaunchKernelGGL(k_normalize_row, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars + 8, ctx->K, ctx->d_q[to], stop);
+	if (ctx->do_projection) ctx->kt->project_q(1, ctx->K, ctx->d_q[to], ctx->eta_lb, stop, ctx->stream);
 	HIPCHK(hipGetLastError());
 	return MCHIP_OK;
 }
@@ -1155,7 +1156,7 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 			    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream);
 	if (do_mstep) {
 		if (!indiv) {
-			int rc = finalize_shared_eta(ctx, to);
+			int rc = finalize_shared_eta(ctx, to, stop);
 			if (rc) return rc;
 		}
 		hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
@@ -1172,7 +1173,7 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	if (!state || n_steps < 1) return fail(ctx, MCHIP_ERR_INVALID, "em_run: bad arguments%s", nullptr);
-	if (!ctx->admixture || !ctx->qstride) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "em_run: admixture model with individual mixing proportions only%s", nullptr);
+	if (!ctx->admixture) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "em_run: admixture model only%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(ctx->d_run, state, sizeof *state, hipMemcpyHostToDevice, ctx->stream));
 	const int *stop = &ctx->d_run->stopped;
@@ -1608,8 +1609,8 @@ int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchi
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	if (!state || n_cycles < 1 || scheme < 1 || scheme > 4) return fail(ctx, MCHIP_ERR_INVALID, "accel_run: bad arguments%s", nullptr);
-	if (!ctx->admixture || !ctx->qstride || !ctx->sparse || ctx->nsec < 1)
-		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "accel_run: admixture model with individual mixing proportions, sparse path, one secant pair%s", nullptr);
+	if (!ctx->admixture || !ctx->sparse || ctx->nsec < 1)
+		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "accel_run: admixture model, sparse path, one secant pair%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(ctx->d_run, state, sizeof *state, hipMemcpyHostToDevice, ctx->stream));
 	/* does Spart hold the S-side sums of this very slot (mchip_loglik_prefetch, or the accepted cycle that ended the

@@ -708,7 +708,7 @@ void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod)
 		if (!mod->fatal) mod->logL = mc_log_likelihood(opt, dat, mod, mod->tindex);
 		return;
 	}
-	if (!opt->accel_scheme && opt->admixture && !opt->eta_constrained && opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
+	if (!opt->accel_scheme && opt->admixture && opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
 	    !getenv("MC_NO_BATCH") && em_batched(opt, mod) == 0)
 		return;
 	while (mod->n_iter < opt->n_init_iter && !stop)
@@ -719,7 +719,7 @@ void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod)
 	}
 	if (mod->converged || mod->fatal) return;
 	if (opt->accel_scheme >= MC_SQS1 && opt->accel_scheme <= MC_QN && opt->q == 1 && !opt->adjust_step && !stop &&
-	    opt->admixture && !opt->eta_constrained && opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
+	    opt->admixture && opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
 	    !getenv("MC_NO_BATCH") && em_accel_batched(opt, mod) == 0)
 		return;
 	do {

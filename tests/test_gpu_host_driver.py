@@ -187,7 +187,7 @@ def test_fit_units_with_jump_ahead_vs_serial_reference(name):
     fit.close()
 
 
-@pytest.mark.parametrize("name", ["multi_admix_k4", "missing_admix_k3", "tetra_admix_k3"])
+@pytest.mark.parametrize("name", ["multi_admix_k4", "missing_admix_k3", "tetra_admix_k3", "multi_admix_c_k3"])
 def test_batched_em_equals_step_by_step(name, monkeypatch):
     """mc_em's batched loop (stopping rule on the device, mchip_em_run) against the step-by-step loop: same stopping
     iteration, bitwise the same log likelihood and parameters."""
@@ -220,7 +220,7 @@ def test_batched_em_iteration_cap_and_decrease_detection():
 
 
 @pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "multi_admix_k4_s1", "multi_admix_k4_s2",
-                                  "multi_admix_k3_qn1", "tetra_admix_k3", "missing_admix_k3"])
+                                  "multi_admix_k3_qn1", "tetra_admix_k3", "missing_admix_k3", "multi_admix_c_k3"])
 def test_batched_accelerated_run_equals_cycle_by_cycle(name, monkeypatch):
     """mc_em with an acceleration scheme runs its cycles in device-side batches (mchip_accel_run: stop rule, step size and
     accept test decided by one-thread kernels, one captured graph per cycle).  Same arithmetic as the cycle-by-cycle host
