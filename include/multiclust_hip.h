@@ -114,8 +114,7 @@ int mchip_last_loglik(mchip_context *ctx, double *loglik);
  * enqueued without a host round trip per iteration; once the rule fires (convergence, iteration cap, NaN, decrease) the
  * remaining steps of the batch are no-ops, so parameters, n_iter and logL are those of the stopping iteration.
  * `state` is in/out: the host seeds it with model::logL / n_iter and reads back where the loop stands.
- * Available for the admixture model (individual or shared mixing proportions); otherwise MCHIP_ERR_UNSUPPORTED (the
- * caller then iterates mchip_em_step).
+ * Available for every model (admixture with individual or shared mixing proportions, mixture).
  */
 typedef struct mchip_run_state {
 	double logL;		/* model::logL: log likelihood of the previous iteration (in), of the last executed one (out) */

@@ -470,10 +470,10 @@ __global__ void k_normalize_row(const double *__restrict__ sums, int K, double *
 
 /* mixture model: log P table; the E step skips p == 0 cells (em_alg.c:797-804), logL_mixture does not
  * (log_likelihood.c:197-200) */
-__global__ void k_logp(const double *__restrict__ p, double *__restrict__ out, size_t n, int skip_zero)
+__global__ void k_logp(const double *__restrict__ p, double *__restrict__ out, size_t n, int skip_zero, const int *stop = nullptr)
 {
 	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= n) return;
+	if (idx >= n || (stop && *stop)) return;
 	const double v = p[idx];
 	out[idx] = (skip_zero && v == 0.0) ? 0.0 : log(v);
 }
@@ -1094,30 +1094,32 @@ static int finalize_shared_eta(mchip_context *ctx, int to, const int *stop = nul
 }
 
 /* mixture model: E step (mode 0, optionally followed by the M step) or logL_mixture (mode 1) */
-static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int mode)
+static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int mode, const int *stop = nullptr)
 {
 	const size_t KT = (size_t)ctx->K * ctx->T;
-	hipLaunchKernelGGL(k_logp, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[from], ctx->d_logp, KT, mode == 0);
+	hipLaunchKernelGGL(k_logp, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[from], ctx->d_logp, KT, mode == 0, stop);
 	mchip_pass_args a = pass_args(ctx, from);
 	a.P = ctx->d_logp;
+	a.stop = stop;
 	prof_mark(ctx, mode == 0 ? MCHIP_KERN_ACCUM_Q : MCHIP_KERN_LOGLIK, true);
 	ctx->kt->mix_gather(a, ctx->stream);
 	prof_mark(ctx, mode == 0 ? MCHIP_KERN_ACCUM_Q : MCHIP_KERN_LOGLIK, false);
 	const int nb = (ctx->I + MCHIP_BLOCK - 1) / MCHIP_BLOCK;
-	ctx->kt->mix_finalize(ctx->I, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[from], ctx->d_sik, ctx->d_llpart, mode, ctx->stream);
-	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, nb, ctx->d_scalars + (mode ? 1 : 0));
+	ctx->kt->mix_finalize(ctx->I, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[from], ctx->d_sik, ctx->d_llpart, mode, stop, ctx->stream);
+	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, nb, ctx->d_scalars + (mode ? 1 : 0), stop);
 	if (do_mstep) {
-		int rc = finalize_shared_eta(ctx, to);		/* em_alg.c:916-962 */
+		int rc = finalize_shared_eta(ctx, to, stop);		/* em_alg.c:916-962 */
 		if (rc) return rc;
 		mchip_pass_args b = pass_args(ctx, from);
 		b.Q = ctx->d_sik;				/* vik rows */
 		b.qstride = ctx->K;
+		b.stop = stop;
 		prof_mark(ctx, MCHIP_KERN_ACCUM_P, true);
 		ctx->kt->mix_column(b, ctx->stream);
 		prof_mark(ctx, MCHIP_KERN_ACCUM_P, false);
 		hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
 				   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
-				   0, ctx->p_lb, ctx->do_projection, ctx->p_lb, ctx->d_flags);
+				   0, ctx->p_lb, ctx->do_projection, ctx->p_lb, ctx->d_flags, stop);
 	}
 	HIPCHK(hipGetLastError());
 	if (mode == 0) ctx->have_ll = 1;
@@ -1126,7 +1128,7 @@ static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int m
 
 static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const int *stop = nullptr, const int *skip_ind = nullptr)
 {
-	if (!ctx->admixture) return run_mixture(ctx, from, to, do_mstep, 0);
+	if (!ctx->admixture) return run_mixture(ctx, from, to, do_mstep, 0, stop);
 	mchip_pass_args a = pass_args(ctx, from);
 	a.stop = stop;
 	a.skip_ind = skip_ind;
@@ -1173,7 +1175,6 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	if (!state || n_steps < 1) return fail(ctx, MCHIP_ERR_INVALID, "em_run: bad arguments%s", nullptr);
-	if (!ctx->admixture) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "em_run: admixture model only%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(ctx->d_run, state, sizeof *state, hipMemcpyHostToDevice, ctx->stream));
 	const int *stop = &ctx->d_run->stopped;

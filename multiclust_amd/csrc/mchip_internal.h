@@ -74,7 +74,8 @@ struct mchip_ktable {
 	void (*project_q)(int nrows, int K, double *Q, double lb, const int *stop, hipStream_t s);
 	/* mixture model */
 	void (*mix_gather)(const mchip_pass_args &a, hipStream_t s);	/* a.P = log P table; Spart = per-chunk sums */
-	void (*mix_finalize)(int I, int n_lchunks, const double *Vpart, const double *eta, double *vik, double *llpart, int mode, hipStream_t s);
+	void (*mix_finalize)(int I, int n_lchunks, const double *Vpart, const double *eta, double *vik, double *llpart, int mode,
+			     const int *stop, hipStream_t s);
 	void (*mix_column)(const mchip_pass_args &a, hipStream_t s);	/* a.Q = vik; Apart = sum_i vik n */
 };
 

@@ -580,6 +580,7 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 template <int PL, bool STAGED>
 __global__ __launch_bounds__(QBLOCK) void k_mix_gather(mchip_pass_args a)
 {
+	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
 	extern __shared__ __attribute__((aligned(16))) double lds[];
 	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
 	const bool active = i_raw < a.I;
@@ -636,9 +637,10 @@ __global__ __launch_bounds__(QBLOCK) void k_mix_gather(mchip_pass_args a)
  *   mode 0 (e_step_mixture, em_alg.c:828-882): v = log eta + sum; max; vik = exp(v - max) / sum; ll_i = log(sum) + max
  *   mode 1 (logL_mixture, log_likelihood.c:203-228): v = sum + log eta; scale only if exp(max) under/overflows */
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_mix_finalize(int I, int n_lchunks, const double *__restrict__ Vpart,
-		const double *__restrict__ eta, double *vik, double *llpart, int mode)
+		const double *__restrict__ eta, double *vik, double *llpart, int mode, const int *stop)
 {
 	__shared__ double red[MCHIP_BLOCK];
+	if (stop && *stop) return;
 	const int i = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
 	double ll = 0.0;
 	if (i < I) {
@@ -698,6 +700,7 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_mix_finalize(int I, int n_lchun
 template <int PL>
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_mix_column(mchip_pass_args a)
 {
+	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
 	const int c_raw = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
 	const bool valid = c_raw < a.T;
 	const int c = valid ? c_raw : a.T - 1;
@@ -931,9 +934,9 @@ void launch_mix_gather(const mchip_pass_args &a, hipStream_t s)
 		else hipLaunchKernelGGL((k_mix_gather<0, false>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
 	}
 }
-void launch_mix_finalize(int I, int n_lchunks, const double *Vpart, const double *eta, double *vik, double *llpart, int mode, hipStream_t s)
+void launch_mix_finalize(int I, int n_lchunks, const double *Vpart, const double *eta, double *vik, double *llpart, int mode, const int *stop, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_mix_finalize, dim3((I + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s, I, n_lchunks, Vpart, eta, vik, llpart, mode);
+	hipLaunchKernelGGL(k_mix_finalize, dim3((I + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s, I, n_lchunks, Vpart, eta, vik, llpart, mode, stop);
 }
 void launch_mix_column(const mchip_pass_args &a, hipStream_t s)
 {

@@ -708,7 +708,7 @@ void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod)
 		if (!mod->fatal) mod->logL = mc_log_likelihood(opt, dat, mod, mod->tindex);
 		return;
 	}
-	if (!opt->accel_scheme && opt->admixture && opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
+	if (!opt->accel_scheme && opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
 	    !getenv("MC_NO_BATCH") && em_batched(opt, mod) == 0)
 		return;
 	while (mod->n_iter < opt->n_init_iter && !stop)

@@ -187,7 +187,8 @@ def test_fit_units_with_jump_ahead_vs_serial_reference(name):
     fit.close()
 
 
-@pytest.mark.parametrize("name", ["multi_admix_k4", "missing_admix_k3", "tetra_admix_k3", "multi_admix_c_k3"])
+@pytest.mark.parametrize("name", ["multi_admix_k4", "missing_admix_k3", "tetra_admix_k3", "multi_admix_c_k3", "multi_mix_k3",
+                                  "missing_mix_k2"])
 def test_batched_em_equals_step_by_step(name, monkeypatch):
     """mc_em's batched loop (stopping rule on the device, mchip_em_run) against the step-by-step loop: same stopping
     iteration, bitwise the same log likelihood and parameters."""
