@@ -120,31 +120,35 @@ template <typename Tp> struct scoped_dev {
 __global__ void k_relayout(const uint8_t *__restrict__ raw, int I, int L, int pl, const int32_t *__restrict__ ua,
 			   int limit, uint8_t *gtA, uint8_t *gtS, size_t nA, size_t nS, int *bad)
 {
-	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx < nA) {
-		size_t r = idx;
-		const int a = (int)(r % pl); r /= pl;
-		const int j = (int)(r % 8); r /= 8;
-		const int l = (int)(r % L);
-		const size_t ib = r / L;
-		const size_t i = ib * 8 + j;
-		uint8_t v = 0xFF;
-		if (i < (size_t)I) {
-			v = raw[(i * L + l) * pl + a];
-			const int lim = ua ? ua[l] : limit;
-			if (v != 0xFF && (int)v >= lim) atomicOr(bad, 1);
-			if (v == 0xFF) atomicOr(bad, 2);	/* bit 1: the data set has missing copies */
+	/* grid-stride: a launch cannot have 2^32 work-items, and a config-3-sized data set already has 2e9 bytes per layout */
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	const size_t nmax = nA > nS ? nA : nS;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nmax; idx += stride) {
+		if (idx < nA) {
+			size_t r = idx;
+			const int a = (int)(r % pl); r /= pl;
+			const int j = (int)(r % 8); r /= 8;
+			const int l = (int)(r % L);
+			const size_t ib = r / L;
+			const size_t i = ib * 8 + j;
+			uint8_t v = 0xFF;
+			if (i < (size_t)I) {
+				v = raw[(i * L + l) * pl + a];
+				const int lim = ua ? ua[l] : limit;
+				if (v != 0xFF && (int)v >= lim) atomicOr(bad, 1);
+				if (v == 0xFF) atomicOr(bad, 2);	/* bit 1: the data set has missing copies */
+			}
+			gtA[idx] = v;
 		}
-		gtA[idx] = v;
-	}
-	if (idx < nS) {
-		size_t r = idx;
-		const int a = (int)(r % pl); r /= pl;
-		const int j = (int)(r % 8); r /= 8;
-		const size_t i = r % I;
-		const size_t lb = r / I;
-		const size_t l = lb * 8 + j;
-		gtS[idx] = (l < (size_t)L) ? raw[(i * L + l) * pl + a] : (uint8_t)0xFF;
+		if (idx < nS) {
+			size_t r = idx;
+			const int a = (int)(r % pl); r /= pl;
+			const int j = (int)(r % 8); r /= 8;
+			const size_t i = r % I;
+			const size_t lb = r / I;
+			const size_t l = lb * 8 + j;
+			gtS[idx] = (l < (size_t)L) ? raw[(i * L + l) * pl + a] : (uint8_t)0xFF;
+		}
 	}
 }
 
@@ -289,13 +293,14 @@ __global__ __launch_bounds__(256) void k_simulate_admixture(rng_window base, con
 /* gtA -> raw [I][L][pl] (mchip_get_genotypes) */
 __global__ void k_unlayout(const uint8_t *__restrict__ gtA, int I, int L, int pl, uint8_t *raw)
 {
-	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= (size_t)I * L * pl) return;
-	size_t r = idx;
-	const int a = (int)(r % pl); r /= pl;
-	const int l = (int)(r % L);
-	const size_t i = r / L;
-	raw[idx] = gtA[(((i >> 3) * L + l) * 8 + (i & 7)) * (size_t)pl + a];
+	const size_t n = (size_t)I * L * pl, stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+		size_t r = idx;
+		const int a = (int)(r % pl); r /= pl;
+		const int l = (int)(r % L);
+		const size_t i = r / L;
+		raw[idx] = gtA[(((i >> 3) * L + l) * 8 + (i & 7)) * (size_t)pl + a];
+	}
 }
 
 /* gtA -> packed counts gtC[g][c]: thread = (group g of G individuals, column c) */
@@ -613,6 +618,12 @@ __global__ void k_select_copy(double *dst, const double *__restrict__ if_accepte
 
 /* ------------------------------------------------------------------ helpers */
 static inline unsigned nblk(size_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b); }
+/* for the byte-per-thread layout kernels (grid-stride loops): at most 2^30 work-items per launch */
+static inline unsigned nblk_capped(size_t n, unsigned b = 256)
+{
+	const size_t blocks = (n + b - 1) / b, cap = ((size_t)1 << 30) / b;
+	return (unsigned)(blocks < cap ? blocks : cap);
+}
 
 static int check_slot(mchip_context *ctx, int slot)
 {
@@ -815,7 +826,7 @@ static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
 	int *d_bad = bad_flag(ctx);
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
-	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_raw, I, L, ploidy, ctx->d_ua, 0,
+	hipLaunchKernelGGL(k_relayout, dim3(nblk_capped(nmax)), dim3(256), 0, ctx->stream, d_raw, I, L, ploidy, ctx->d_ua, 0,
 			   ctx->d_gtA, ctx->d_gtS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
@@ -876,7 +887,7 @@ int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
 	HIPCHK(hipMemcpyAsync(d_obs, geno, n, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
-	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_obs.p, ctx->I, ctx->L, ctx->ploidy, ctx->d_ua, 0,
+	hipLaunchKernelGGL(k_relayout, dim3(nblk_capped(nmax)), dim3(256), 0, ctx->stream, d_obs.p, ctx->I, ctx->L, ctx->ploidy, ctx->d_ua, 0,
 			   ctx->d_initA, ctx->d_initS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
@@ -898,7 +909,7 @@ int mchip_get_genotypes(mchip_context *ctx, uint8_t *geno)
 	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
 	scoped_dev<uint8_t> d_raw;
 	HIPCHK(d_raw.alloc(n));
-	hipLaunchKernelGGL(k_unlayout, dim3(nblk(n)), dim3(256), 0, ctx->stream, ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, d_raw.p);
+	hipLaunchKernelGGL(k_unlayout, dim3(nblk_capped(n)), dim3(256), 0, ctx->stream, ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, d_raw.p);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(geno, d_raw, n, hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -913,6 +924,9 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 	if (K < 1) return fail(ctx, MCHIP_ERR_INVALID, "K must be >= 1%s", nullptr);
 	if (K > MCHIP_MAX_K) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "K > MCHIP_MAX_K is not built%s", nullptr);
 	if (n_secants < 0 || n_secants > MCHIP_MAX_SECANTS) return fail(ctx, MCHIP_ERR_INVALID, "n_secants out of range%s", nullptr);
+	/* the element-per-thread kernels over parameters take one work-item per entry of P or Q */
+	if ((size_t)K * ctx->T >= ((size_t)1 << 31) || (size_t)K * ctx->I >= ((size_t)1 << 31))
+		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "K*T or K*I of 2^31 or more is not supported%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	free_model(ctx);
@@ -1285,7 +1299,7 @@ static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to)
 	int *d_bad = bad_flag(ctx);
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
-	hipLaunchKernelGGL(k_relayout, dim3(nblk(nmax)), dim3(256), 0, ctx->stream, d_raw, ctx->I, ctx->L, ctx->ploidy,
+	hipLaunchKernelGGL(k_relayout, dim3(nblk_capped(nmax)), dim3(256), 0, ctx->stream, d_raw, ctx->I, ctx->L, ctx->ploidy,
 			   (const int32_t *)nullptr, ctx->K, ctx->d_asA, ctx->d_asS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
