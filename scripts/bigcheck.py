@@ -3,7 +3,8 @@
   * one EM step on the full data set: sum of expected counts = number of observed copies; parameters stay normalised
   * logL(full) = logL(first half of the individuals) + logL(second half) for the same P (separate uploads)
   * the device-drawn partition at this size: its per-individual counts for the LAST individuals equal those from the
-    host stream jumped to their first draw (the jump polynomials of the high chunks are exercised)"""
+    host stream jumped to their first draw (the jump polynomials of the high chunks are exercised); the same for a
+    device-generated bootstrap data set (9.6e9 draws)"""
 import ctypes as C
 import os
 import sys
@@ -65,6 +66,24 @@ for k in range(K):
     exp[:, k] = hit.sum(axis=(1, 2)) - both_same.sum(axis=1)
 assert np.array_equal(cnt[I - tail:], exp), (cnt[I - tail:][:2], exp[:2])
 print("device-drawn partition: last %d individuals match the host stream at draw offset %.3e" % (tail, (I - tail) * L * P), flush=True)
+# device-generated bootstrap data set at this size (9.6e9 draws): the last individuals against the host generator
+hl.mc_srand(C.byref(rng), 77)
+window = np.array([rng.r[(rng.f + t) % 31] for t in range(31)], dtype=np.int64).astype(np.uint32)
+ctx.simulate_genotypes(I, L, P, ua, window, K, q0, p0)
+sim_tail = ctx.get_genotypes()[I - tail:]
+hl.mc_rng_jump(C.byref(rng), 2 * (I - tail) * L * P)
+opt = host.McOptions()
+hl.mc_make_options(C.byref(opt))
+opt.admixture = 1
+ua32 = np.ascontiguousarray(ua, dtype=np.int32)
+g_dummy = np.ascontiguousarray(geno[I - tail:])
+dat = host.McData(tail, L, P, ua32.ctypes.data, g_dummy.ctypes.data, None)
+q_tail = np.ascontiguousarray(q0[I - tail:])
+ref = np.empty((tail, L, P), dtype=np.uint8)
+hl.mc_bootstrap_genotypes(C.byref(opt), C.byref(dat), K, q_tail.ctypes.data, p0.ctypes.data, C.byref(rng), ref.ctypes.data)
+assert np.array_equal(sim_tail, ref)
+print("device-generated bootstrap data set: last %d individuals match the host generator at draw offset %.3e" % (tail, 2 * (I - tail) * L * P), flush=True)
+ctx.set_genotypes(ua, geno)
 del ctx
 # halves
 lls = []
