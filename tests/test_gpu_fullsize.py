@@ -100,3 +100,58 @@ def test_config3_full_size_properties_and_slice_against_oracle():
     u2 = float(((q2 - q0) ** 2).sum() + ((p2 - p0) ** 2).sum())
     assert abs(d[0] - u2) <= 1e-9 * u2
     ctx.close()
+
+
+def test_beyond_2_pow_32_allele_copies():
+    """22 000 x 100 000 diploid = 4.4e9 allele copies: more bytes per genotype layout than a launch has work-items.
+    Identities that hold at any size: the genotype comes back from the device layouts; logL(all individuals) =
+    logL(first half) + logL(second half) for the same P; the device-drawn partition of the last individuals equals the
+    oracle's glibc stream advanced to their first draw (4.4e9 draws in: the high jump polynomials)."""
+    import ctypes as C
+    from multiclust_amd import host
+    I, L, P, K = 22000, 100000, 2, 3
+    rs = np.random.default_rng(3)
+    ua = rs.integers(2, 5, L).astype(np.int32)
+    base = rs.integers(0, 12, (64, L, P), dtype=np.uint8)              # 64 random individuals, tiled with a per-row shift
+    geno = np.empty((I, L, P), dtype=np.uint8)
+    for i0 in range(0, I, 64):
+        n = min(64, I - i0)
+        geno[i0:i0 + n] = (base[:n] + np.uint8(i0 // 64 % 12)) % ua[None, :, None].astype(np.uint8)
+    q0, p0 = random_params(I, ua, K, seed=2)
+    ctx = mc.Context(0)
+    ctx.set_genotypes(ua, geno)
+    assert np.array_equal(ctx.get_genotypes(), geno)
+    ctx.set_model(K, lower_bound=1e-8)
+    ctx.set_q(0, q0)
+    ctx.set_p(0, p0)
+    ll_full = ctx.loglik(0)
+    ctx.em_step(0, 1)
+    assert abs(ctx.expected_counts().sum() - I * L * P) <= 1e-9 * I * L * P
+    # device-drawn partition, last individuals (all loci heterozygous or not: d_iklm is an indicator, so a homozygote whose
+    # two copies draw the same cluster counts once)
+    hl = host.load()
+    rng = host.McRng()
+    hl.mc_srand(C.byref(rng), 99)
+    window = np.array([rng.r[(rng.f + t) % 31] for t in range(31)], dtype=np.int64).astype(np.uint32)
+    ctx.mstep_from_rand_partition(window, 2)
+    cnt = ctx.expected_counts()
+    tail = 3
+    hl.mc_rng_jump(C.byref(rng), (I - tail) * L * P)
+    d = np.fromiter((hl.mc_rand(C.byref(rng)) % K for _ in range(tail * L * P)), dtype=np.int64, count=tail * L * P).reshape(tail, L, P)
+    g = geno[I - tail:]
+    exp = np.zeros((tail, K))
+    for k in range(K):
+        hit = d == k
+        exp[:, k] = hit.sum(axis=(1, 2)) - (hit[:, :, 0] & hit[:, :, 1] & (g[:, :, 0] == g[:, :, 1])).sum(axis=1)
+    assert np.array_equal(cnt[I - tail:], exp)
+    ctx.close()
+    lls = []
+    for sl in (slice(0, I // 2), slice(I // 2, I)):
+        c = mc.Context(0)
+        c.set_genotypes(ua, geno[sl])
+        c.set_model(K, lower_bound=1e-8)
+        c.set_q(0, q0[sl])
+        c.set_p(0, p0)
+        lls.append(c.loglik(0))
+        c.close()
+    assert abs(sum(lls) - ll_full) <= 1e-11 * abs(ll_full), (lls, ll_full)
