@@ -1,28 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py -- EM iterations/s of the MI355X EM hot path on BASELINE.json's workload.
+"""bench.py -- EM iterations/s of the MI355X EM hot path on BASELINE.json's workloads.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--workload c3|c4|c5|c2|c1|c5fit]
 
-Workload (default "c3", BASELINE.json configs[2], the configuration north_star's target is quoted on):
-10 000 diploid individuals x 100 000 loci, M_l ~ U{2,3,4} alleles, admixture K = 8, SQUAREM-3 (-s 3), one
-initialisation per GPU.  A "step" is one pass of the hot path as the reference sequences it for -s 3: one
-accelerated_em_step() cycle = 2 EM iterations (E+M, n_iter += 2) + 2 stand-alone log-likelihood passes +
-step size + extrapolation/projection (accel_em.c:35-114), driven by the plain-C host side over the C-ABI.
-value = EM iterations/s summed over ranks (n_iter increments / wall time), inputs resident in HBM.
+With N > 1 and no RANK in the environment this process only checks that N devices are visible and starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a
+child (before anything touches the GPU; a child process, never an exec) and exits with its code; launched by
+torch.distributed.run itself (RANK set) it is one rank of N, one rank per GPU over RCCL.
 
-Multi-GPU: the path shards by independent units (random initialisations, multiclust.c:516-653): rank r fits
-its own initialisation on its own GPU with no data-path collective; one RCCL all-reduce (MAX) picks the best
-log likelihood at the end (inside the timed region).  scaling = "weak".
+Workloads
+  c3 (default; BASELINE.json configs[2], the configuration north_star's target is quoted on): 10 000 diploid individuals x
+     100 000 loci, M_l ~ U{2,3,4}, admixture K = 8, SQUAREM-3 (-s 3), one initialisation per GPU.  A step is one
+     accelerated_em_step() cycle = 2 EM iterations + 2 stand-alone log-likelihood passes + step size + extrapolation and
+     projection (accel_em.c:35-114).  scaling = "weak": rank r fits unit r of the serial program's rand() stream.
+  c4 (configs[3]): the same data and model, `--units` (50) random initialisations sharded unit u -> rank u mod N
+     (multiclust.c:516-653), every unit = device-side initialisation from its position in the serial rand() stream + K
+     SQUAREM cycles (-T 2K-1), all inside the timed region; one all-reduce completes the per-unit result table, every rank
+     replays the serial bookkeeping.  scaling = "strong" (the 50 units are the job).
+  c5 (configs[4]): 5 000 tetraploid individuals x 50 000 loci, bootstrap of K = 7 against K = 8 (-b 200): replicate b ->
+     rank b mod N (multiclust.c:675-708); a replicate = data set generated on the device from the H0 fit at the
+     replicate's position in the rand() stream + one initialisation and K+1 plain EM iterations (-T K) of each model; one
+     all-reduce completes the table of test statistics.  scaling = "strong".
+  c2, c1, c5fit: single fits at the shapes of configs[1], configs[0] and configs[4] (plain EM), measured like c3.
 
-Also reported on the same JSON line: `roofline` for the dominant kernel (HIP events on the library's own
-stream) and `cpu_baseline` (the CPU oracle, timed on a bounded sample on rank 0 at N = 1 only; the oracle is
-used here only as the baseline, never as the measured path).  `cpu_baseline.parity` is the metric's "logL delta vs ref":
-the HIP path run on that same sample from the same parameters for the same iterations, against the oracle's result.
+value = EM iterations/s summed over ranks (n_iter increments of stop(), em_alg.c:103, over the barrier-to-barrier wall time,
+max over ranks), inputs resident in HBM.  The same JSON line carries `roofline` for the dominant kernel (HIP events on the
+library's own stream) and, at N = 1, `cpu_baseline` (the CPU oracle on a bounded sample, rank 0; the oracle is only the
+baseline and the checker here, never the measured path) with `parity` = the HIP path on that same sample against it.
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,20 +46,94 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6    # vector FP64 peak (spec), for the secondary fraction only
 FP64_VALU_MEASURED_TF = 70.5 # best v_fma_f64 rate measured on this chip (profiles/r01_fp64_microbench.txt)
+SEED = 1234567              # -r of every run below
 
 WORKLOADS = {
-    # name: I, L, ploidy, max alleles, K, accel scheme, description
-    "c3": dict(I=10000, L=100000, ploidy=2, maxal=4, K=8, accel=3,
+    # name: I, L, ploidy, max alleles, K, accel scheme, data seed offset, description
+    "c3": dict(I=10000, L=100000, ploidy=2, maxal=4, K=8, accel=3, dseed=3,
                desc="10000 diploid x 100000 loci, M_l~U{2,3,4}, admixture K=8, SQUAREM-3 (-s 3)"),
-    "c2": dict(I=2000, L=20000, ploidy=2, maxal=2, K=5, accel=0,
+    "c4": dict(I=10000, L=100000, ploidy=2, maxal=4, K=8, accel=3, dseed=3,
+               desc="10000 diploid x 100000 loci, M_l~U{2,3,4}, admixture K=8, SQUAREM-3, random initialisations sharded over GPUs"),
+    "c5": dict(I=5000, L=50000, ploidy=4, maxal=4, K=8, accel=0, dseed=5,
+               desc="5000 tetraploid x 50000 loci, M_l~U{2,3,4}, bootstrap of K=7 vs K=8, replicates sharded over GPUs"),
+    "c2": dict(I=2000, L=20000, ploidy=2, maxal=2, K=5, accel=0, dseed=2,
                desc="2000 diploid x 20000 biallelic loci, admixture K=5, plain EM (-s 0)"),
-    "c1": dict(I=100, L=500, ploidy=2, maxal=2, K=3, accel=0,
+    "c1": dict(I=100, L=500, ploidy=2, maxal=2, K=3, accel=0, dseed=1,
                desc="100 diploid x 500 biallelic loci, admixture K=3, plain EM"),
-    "c5": dict(I=5000, L=50000, ploidy=4, maxal=4, K=8, accel=0,
-               desc="5000 tetraploid x 50000 loci, M_l~U{2,3,4}, admixture K=8, plain EM"),
+    "c5fit": dict(I=5000, L=50000, ploidy=4, maxal=4, K=8, accel=0, dseed=5,
+                  desc="5000 tetraploid x 50000 loci, M_l~U{2,3,4}, admixture K=8, plain EM, single fit"),
 }
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(n):
+    """--gpus N without RANK: start the N ranks as a child process.  torch.cuda.device_count() does not initialise the
+    GPU on this image; nothing else here touches it."""
+    if "MC_BENCH_DEVICE" not in os.environ:            # rehearsal knob: all ranks share that one device
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n" % (n, have))
+            sys.exit(3)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+class Env:
+    """rank, device and the process group (torch is plumbing: device memory for the synthetic data, the collective)"""
+
+    def __init__(self, gpus):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (gpus, self.world))
+        import torch
+        self.torch = torch
+        # rehearsal knobs (not used by the driver): several ranks on ONE GPU need gloo and a shared device index
+        self.backend = os.environ.get("MC_BENCH_BACKEND", "nccl")
+        if "MC_BENCH_DEVICE" in os.environ:
+            self.local_rank = int(os.environ["MC_BENCH_DEVICE"])
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        if self.local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d has no device %d" % (self.rank, self.local_rank))
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
+        self.cdev = self.dev if self.backend == "nccl" else torch.device("cpu")      # where the collective's tensors live
+
+    def barrier(self, ctx=None):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        if ctx is not None:
+            from multiclust_amd import hip
+            hip.load().mchip_synchronize(ctx)
+
+    def reduce(self, values, op):
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.cdev)
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return t.cpu().tolist()
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ data
 def gen_dataset(I, L, K, ploidy, maxal, seed, device):
     """SURVEY.md 8d generator on the GPU (torch is plumbing here): P_kl ~ Dirichlet(0.5), Q_i ~ Dirichlet(0.2),
     z ~ Cat(Q_i) per allele copy, allele ~ Cat(P_z,l).  Returns host arrays (the C-ABI takes host buffers)."""
@@ -79,11 +165,17 @@ def gen_dataset(I, L, K, ploidy, maxal, seed, device):
         a = (u2[..., None] > c[..., :M - 1]).sum(dim=3)
         a = torch.minimum(a, (ua[None, :, None] - 1))
         geno[i0:i1] = a.to(torch.uint8).cpu().numpy()
+    torch.cuda.empty_cache()
     return ua.to(torch.int32).cpu().numpy(), geno
 
 
-def algorithmic_bytes(w, T):
-    I, L, p, K = w["I"], w["L"], w["ploidy"], w["K"]
+def workload_data(w, env):
+    return gen_dataset(w["I"], w["L"], w["K"], w["ploidy"], w["maxal"], 20250117 + w["dseed"], env.dev)
+
+
+def algorithmic_bytes(w, T, K=None):
+    I, L, p = w["I"], w["L"], w["ploidy"]
+    K = K or w["K"]
     g = I * L * p
     return {
         "iteration": g + 16 * K * T + 16 * I * K,            # B_it
@@ -93,6 +185,7 @@ def algorithmic_bytes(w, T):
     }
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline + parity
 def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0):
     """The CPU oracle (oracle/mc_oracle.c, fused order, one host core) on a bounded sample of the same
     workload: the first L_s loci of every individual, sized for about `budget_s` seconds."""
@@ -146,111 +239,99 @@ def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0):
     }
 
 
-def secondary_run(name, dev, local_rank, steps=300):
-    """A second, smaller BASELINE.json configuration measured the same way (plain numbers only), so that one bench line
-    carries both single-GPU configurations: configs[1] (c2) next to the headline configs[2] (c3)."""
+# ------------------------------------------------------------------------------------------------ roofline object
+def latest_traffic(tag):
+    """HBM bytes per launch from the PMC passes of this same command (scripts/summarize_profile.py; corrected as
+    MI355X_MICROARCH.md prescribes): the newest profiles/r*_<tag>_traffic.json, or None"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_traffic.json" % tag)))
+    return json.load(open(files[-1])) if files else None
+
+
+def profile_begin(ctx):
+    from multiclust_amd import hip
+    hip.load().mchip_profile_begin(ctx)
+
+
+def roofline_object(ctx, w, T, K, it_per_s_per_gpu, workload, nnz):
+    from multiclust_amd import hip
+    hlib = hip.load()
+    total_ms = C.c_double()
+    km = (C.c_double * hip.PROF_KINDS)()
+    kl = (C.c_int * hip.PROF_KINDS)()
+    hlib.mchip_profile_end(ctx, C.byref(total_ms), km, kl)
+    B = algorithmic_bytes(w, T, K)
+    names = ["column_pass", "individual_pass", "loglik_pass"]
+    avg = [km[x] / kl[x] if kl[x] else 0.0 for x in range(hip.PROF_KINDS)]
+    dom = max(range(2), key=lambda x: avg[x])
+    ach = B[names[dom]] / (avg[dom] * 1e-3) / 1e9 if avg[dom] else 0.0
+    flops_cell = 5 * K + 5                                   # SURVEY.md 8d: flops per non-empty cell (+ one log)
+    traffic = None
+    tj = latest_traffic("c3") if workload in ("c3", "c4") else None
+    if tj:
+        want = "k_column_counts" if dom == 0 else "k_individual_sparse<2, true"
+        for name, rec in tj.items():
+            if name.startswith(want):
+                traffic = rec.get("hbm_bytes_per_launch_corrected")
+                break
+    return {
+        "bound": "hbm", "kernel": "k_column_counts (N-side sums)" if dom == 0 else "k_individual_sparse (S-side sums + logL)",
+        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+        "algorithmic_bytes_per_launch": B[names[dom]], "avg_launch_ms": avg[dom],
+        "kernels_ms": {names[x]: avg[x] for x in range(hip.PROF_KINDS)},
+        "launches": {names[x]: kl[x] for x in range(hip.PROF_KINDS)},
+        "iteration_bytes": B["iteration"],
+        "iteration_hbm_frac": B["iteration"] * it_per_s_per_gpu / 1e9 / HBM_PEAK_GBS,
+        "nonempty_cells": nnz, "dense_cells": w["I"] * T,
+        "fp64_valu_frac": flops_cell * nnz * it_per_s_per_gpu / 1e12 / FP64_VALU_PEAK_TF,
+        "fp64_valu_frac_dense_cells": flops_cell * w["I"] * T * it_per_s_per_gpu / 1e12 / FP64_VALU_PEAK_TF,
+        "fp64_note": "kernels are FP64-issue-bound, not HBM-bound.  fp64_valu_frac = (5K+5) flop per NON-EMPTY cell (SURVEY.md 8d; "
+                     "cells counted on the device at upload) x iterations/s over the 78.6 TF/s vector-FP64 spec peak (best measured "
+                     "v_fma_f64 rate on this chip: %.1f TF/s); the _dense_cells figure counts every (individual, allele column) "
+                     "cell, which is what the column pass actually multiplies through" % FP64_VALU_MEASURED_TF,
+    }
+
+
+def data_counts(ctx):
+    from multiclust_amd import hip
+    a, b = C.c_uint64(), C.c_uint64()
+    hip.load().mchip_data_counts(ctx, C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
+# ------------------------------------------------------------------------------------------------ single fit per GPU (c3, c2, c1, c5fit)
+def run_single_fit(args, env, name, ua, geno, steps, warmup, with_roofline=True):
     from multiclust_amd import hip, host
     w = WORKLOADS[name]
-    ua, geno = gen_dataset(w["I"], w["L"], w["K"], w["ploidy"], w["maxal"], 20250117 + 2, dev)
-    fit = host.Fit(ua, geno, w["K"], device=local_rank, admixture=1, accel_scheme=w["accel"], verbosity=1, abs_error=1e-300)
-    fit.initialize(1234567)
-    for _ in range(5):
-        fit.em_step()
-    st = hip.RunState(logL=fit.mod.logL, abs_error=1e-300, n_iter=fit.mod.n_iter)
-    lib, ctx = hip.load(), C.c_void_p(fit.mod.dev)
-    lib.mchip_synchronize(ctx)
-    t0 = time.perf_counter()
-    rc = lib.mchip_em_run(ctx, 0, steps, C.byref(st))       # plain EM: one batch, stopping rule on the device
-    dt = time.perf_counter() - t0
-    if rc or st.fatal or st.stopped:
-        raise SystemExit("secondary run failed")
-    out = {"workload": "%s: %s" % (name, w["desc"]), "value": steps / dt, "unit": "EM iterations/s",
-           "ms_per_step": dt * 1e3 / steps, "steps": steps}
-    fit.close()
-    return out
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--accel", type=int, default=None, help="override the workload's acceleration scheme (0..6)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--no-secondary", action="store_true", help="skip the extra config-2 line (profiling runs: its kernels "
-                    "carry the same names as the headline workload's)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    dist = None
-    # rehearsal knobs (not used by the driver): several ranks on ONE GPU need gloo and a shared device index
-    backend = os.environ.get("MC_BENCH_BACKEND", "nccl")
-    if "MC_BENCH_DEVICE" in os.environ:
-        local_rank = int(os.environ["MC_BENCH_DEVICE"])
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    cdev = dev if backend == "nccl" else torch.device("cpu")      # where the collective's tensors live
-
-    from multiclust_amd import hip, host
-    w = dict(WORKLOADS[args.workload])
     accel = w["accel"] if args.accel is None else args.accel
-    ua, geno = gen_dataset(w["I"], w["L"], w["K"], w["ploidy"], w["maxal"], 20250117 + 3, dev)
     T = int(ua.sum())
-    torch.cuda.empty_cache()
-
-    fit = host.Fit(ua, geno, w["K"], device=local_rank, admixture=1, accel_scheme=accel, verbosity=1,
-                   abs_error=1e-300)          # never "converges": exactly K timed steps
+    fit = host.Fit(ua, geno, w["K"], device=env.local_rank, admixture=1, accel_scheme=accel, verbosity=1,
+                   abs_error=1e-300)          # never "converges": exactly `steps` timed steps
     hlib = hip.load()
     ctx = C.c_void_p(fit.mod.dev)
     # one initialisation per rank = unit `rank` of the serial program: random allele partition (rnd_init.c:456-482)
-    # drawn from the glibc-compatible stream jumped ahead to unit * I*L*ploidy draws (mc_rng_jump), first M step on
-    # the device (mchip_mstep_from_partition).  Not timed (the metric is the EM loop).
+    # drawn on the device from the glibc-compatible stream jumped ahead to unit * I*L*ploidy draws, first M step on
+    # the device.  Not timed here (the metric is the EM loop; c4 times it).
     rng = host.McRng()
     hostlib = host.load()
-    hostlib.mc_srand(C.byref(rng), 1234567)
-    hostlib.mc_rng_jump(C.byref(rng), rank * hostlib.mc_draws_per_init(C.byref(fit.opt), C.byref(fit.dat), w["K"]))
+    hostlib.mc_srand(C.byref(rng), SEED)
+    hostlib.mc_rng_jump(C.byref(rng), env.rank * hostlib.mc_draws_per_init(C.byref(fit.opt), C.byref(fit.dat), w["K"]))
     rc = hostlib.mc_initialize_model(C.byref(fit.opt), C.byref(fit.dat), fit.mp, C.byref(rng))
     if rc:
         raise SystemExit("mc_initialize_model failed: %s" % hlib.mchip_last_error(ctx).decode())
 
-    iters_per_step = 2 if accel else 1
-
     def one_step():
-        if accel:
-            fit.accelerated_em_step()
-        else:
-            fit.em_step()
+        fit.accelerated_em_step() if accel else fit.em_step()
         if fit.mod.fatal:
             raise SystemExit("EM stopped with fatal=%d" % fit.mod.fatal)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one_step()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        hlib.mchip_synchronize(ctx)
 
     def run_steps(n):
         """n steps of the hot path as the host driver (mc_em) runs them: ONE batch whose stopping rule -- and, for the
         accelerated schemes, step size and accept test -- runs on the device."""
         st = hip.RunState(logL=fit.mod.logL, abs_error=1e-300, n_iter=fit.mod.n_iter)
         if accel and 1 <= accel <= 4:
-            # one batch of cycles decided on the device (mc_em's own path for -s 1..4)
             rc = hlib.mchip_accel_run(ctx, fit.mod.pindex, accel, n, C.byref(st))
         elif accel:
             for _ in range(n):
@@ -262,78 +343,241 @@ def main():
             raise SystemExit("batched run: rc=%d fatal=%d stopped=%d" % (rc, st.fatal, st.stopped))
         fit.mod.n_iter, fit.mod.logL = st.n_iter, st.logL
 
-    barrier()
+    env.barrier(ctx)
     n_iter0 = fit.mod.n_iter
-    hlib.mchip_profile_begin(ctx)
+    if with_roofline:
+        profile_begin(ctx)
     t0 = time.perf_counter()
-    run_steps(args.steps)
-    best = torch.tensor([fit.mod.logL], dtype=torch.float64, device=cdev)
-    if dist is not None:
-        dist.all_reduce(best, op=dist.ReduceOp.MAX)     # the path's one exchange: best log likelihood over units
-    barrier()
+    run_steps(steps)
+    best = env.reduce([fit.mod.logL], "MAX")[0]     # the path's one exchange: best log likelihood over units
+    env.barrier(ctx)
     dt = time.perf_counter() - t0
-    total_ms = C.c_double()
-    km = (C.c_double * hip.PROF_KINDS)()
-    kl = (C.c_int * hip.PROF_KINDS)()
-    hlib.mchip_profile_end(ctx, C.byref(total_ms), km, kl)
-    n_iter = fit.mod.n_iter - n_iter0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    its = torch.tensor([float(n_iter)], dtype=torch.float64, device=cdev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(its, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
-    total_iters = float(its.item())
+    dt = env.reduce([dt], "MAX")[0]
+    total_iters = env.reduce([float(fit.mod.n_iter - n_iter0)], "SUM")[0]
+    value = total_iters / dt
+    out = {
+        "value": value, "ms_per_step": dt * 1e3 / steps, "steps": steps,
+        "config": {"workload": "%s: %s" % (name, w["desc"]), "I": w["I"], "L": w["L"], "T": T, "ploidy": w["ploidy"], "K": w["K"],
+                   "accel_scheme": accel, "em_iterations_per_step": 2 if accel else 1,
+                   "units": "%d initialisation(s), one per GPU" % env.world, "best_logL": best},
+    }
+    if with_roofline and env.rank == 0:
+        nnz, _ = data_counts(ctx)
+        out["roofline"] = roofline_object(ctx, w, T, w["K"], value / env.world, name, nnz)
+    elif with_roofline:
+        hlib.mchip_profile_end(ctx, None, None, None)
+    return out, fit, accel
 
-    if rank == 0:
-        B = algorithmic_bytes(w, T)
-        names = ["column_pass", "individual_pass", "loglik_pass"]
-        avg = [km[x] / kl[x] if kl[x] else 0.0 for x in range(hip.PROF_KINDS)]
-        dom = max(range(2), key=lambda x: avg[x])
-        ach = B[names[dom]] / (avg[dom] * 1e-3) / 1e9 if avg[dom] else 0.0
-        nnz_flops = (5 * w["K"] + 5) * w["I"] * T          # SURVEY.md 8d, dense-over-columns upper bound
-        value = total_iters / dt
-        # HBM traffic per launch of the dominant kernel: PMC FETCH_SIZE/WRITE_SIZE from separate `rocprofv3 --pmc` passes
-        # of this same command (scripts/summarize_profile.py; corrected as MI355X_MICROARCH.md prescribes), config 3 only
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_v5_c3_traffic.json")
-        if args.workload == "c3" and os.path.exists(tf):
-            want = "k_column_counts<2, false>" if dom == 0 else "k_individual_sparse<2, true, false, true>"
-            traffic = json.load(open(tf)).get(want, {}).get("hbm_bytes_per_launch_corrected")
-        out = {
-            "metric": "EM iterations/sec, IxLxK admixture",
-            "value": value, "unit": "EM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s" % (args.workload, w["desc"]), "I": w["I"], "L": w["L"], "T": T,
-                       "ploidy": w["ploidy"], "K": w["K"], "accel_scheme": accel,
-                       "em_iterations_per_step": iters_per_step, "units": "%d initialisation(s), one per GPU" % world,
-                       "best_logL": float(best.item())},
-            "roofline": {
-                "bound": "hbm", "kernel": "k_column_counts (N-side sums)" if dom == 0 else "k_individual_sparse (S-side sums + logL)",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": B[names[dom]], "avg_launch_ms": avg[dom],
-                "kernels_ms": {names[x]: avg[x] for x in range(hip.PROF_KINDS)},
-                "launches": {names[x]: kl[x] for x in range(hip.PROF_KINDS)},
-                "iteration_bytes": B["iteration"],
-                "iteration_hbm_frac": B["iteration"] * (value / world) / 1e9 / HBM_PEAK_GBS,
-                "fp64_valu_frac": nnz_flops * (value / world) / 1e12 / FP64_VALU_PEAK_TF,
-                "fp64_note": "kernels are FP64-issue-bound, not HBM-bound: (5K+5) flop per cell x I x T per iteration over the 78.6 TF/s "
-                             "vector-FP64 spec peak (best measured v_fma_f64 rate on this chip: %.1f TF/s); PMC counters of the same "
-                             "command at config 3 (profiles/r01_v4_c3_sq_counters.txt): vector ALUs busy 94 %% of the column pass, "
-                             "83 %% of the individual pass" % FP64_VALU_MEASURED_TF,
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget, local_rank)
-            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-    fit.close()
-    if rank == 0:
-        if world == 1 and args.workload == "c3" and not args.no_secondary:
-            out["secondary"] = secondary_run("c2", dev, local_rank)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+
+# ------------------------------------------------------------------------------------------------ c4: initialisations sharded
+def run_units(env, fit, w, T, n_units, cycles, warmup, with_roofline=True):
+    """n_units random initialisations of one data set, unit u on rank u mod N; every unit = mc_fit_unit (stream jumped to the
+    unit's first draw, device-side initialisation, em() with -T 2*cycles-1) and is timed whole."""
+    from multiclust_amd import hip, host, shard
+    hlib = hip.load()
+    ctx = C.c_void_p(fit.mod.dev)
+    accel = fit.opt.accel_scheme
+    per_cycle = 2 if accel else 1
+    fit.opt.abs_error = 1e-300
+    if warmup > 0:                                    # untimed: graph capture, first-touch allocations of the init path
+        fit.opt.max_iter = per_cycle * min(warmup, cycles) - 1
+        fit.fit_unit(SEED, env.rank)
+    fit.opt.max_iter = per_cycle * cycles - 1         # -T n runs n + 1 iterations (em_alg.c:150)
+    mine = shard.units_for_rank(n_units, env.rank, env.world)
+    env.barrier(ctx)
+    if with_roofline:
+        profile_begin(ctx)
+    t0 = time.perf_counter()
+    local = []
+    for u in mine:
+        r = fit.fit_unit(SEED, u)
+        if r.fatal:
+            raise SystemExit("unit %d: fatal=%d" % (u, r.fatal))
+        local.append(r)
+    results = shard.exchange(local, n_units, env.dist, env.cdev)      # the path's one exchange (all-reduce of disjoint rows)
+    env.barrier(ctx)
+    dt = time.perf_counter() - t0
+    dt = env.reduce([dt], "MAX")[0]
+    summary = shard.replay(results, fit.opt, fit.no_parameters(), fit.I)
+    total_iters = sum(r.n_iter for r in results)
+    steps_on_busiest = max(1, len(shard.units_for_rank(n_units, 0, env.world))) * cycles
+    out = {
+        "value": total_iters / dt, "ms_per_step": dt * 1e3 / steps_on_busiest, "steps": cycles,
+        "config": {"workload": "c4: %s" % w["desc"], "I": w["I"], "L": w["L"], "T": T, "ploidy": w["ploidy"], "K": w["K"],
+                   "accel_scheme": accel, "em_iterations_per_step": per_cycle, "units": n_units,
+                   "unit_to_rank": "u mod %d" % env.world, "max_iter": fit.opt.max_iter,
+                   "timed": "rand() jump-ahead + device-side initialisation + em() of every unit + the all-reduce",
+                   "time_to_finish_s": dt, "units_per_s": n_units / dt, "em_iterations": total_iters,
+                   "best_unit": summary.best_unit, "best_logL": summary.max_logL,
+                   "unit_logL": [r.logL for r in results]},
+    }
+    if with_roofline and env.rank == 0:
+        nnz, _ = data_counts(ctx)
+        out["roofline"] = roofline_object(ctx, w, T, w["K"], total_iters / dt / env.world, "c4", nnz)
+    elif with_roofline:
+        hlib.mchip_profile_end(ctx, None, None, None)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ c5: bootstrap replicates sharded
+def run_bootstrap(env, w, ua, geno, n_rep, budget, n_init=1):
+    """-b n_rep of K-1 vs K (multiclust.c:675-708): the observed-data fits (untimed setup, every rank computes the same bits),
+    then replicate b on rank b mod N = mc_fit_replicate, timed whole."""
+    from multiclust_amd import host
+    lib = host.load()
+    K1, K0 = w["K"], w["K"] - 1
+    T = int(ua.sum())
+    opts = dict(admixture=1, accel_scheme=0, verbosity=1, abs_error=1e-300, max_iter=budget)
+    obs = {}
+    for K in (K0, K1):                                  # estimate_model on the observed data: H0 then HA
+        fit = host.Fit(ua, geno, K, device=env.local_rank, **opts)
+        rng = host.McRng()
+        lib.mc_srand(C.byref(rng), SEED)
+        lib.mc_rng_jump(C.byref(rng), (0 if K == K0 else n_init) * lib.mc_draws_per_init(C.byref(fit.opt), C.byref(fit.dat), K))
+        best = None
+        for u in range(n_init):
+            fit.reset()
+            if lib.mc_initialize_model(C.byref(fit.opt), C.byref(fit.dat), fit.mp, C.byref(rng)):
+                raise SystemExit("mc_initialize_model failed")
+            fit.em()
+            if best is None or fit.mod.logL > best[0]:
+                best = (fit.mod.logL, fit.get_q(fit.mod.pindex), fit.get_p(fit.mod.pindex))
+        obs[K] = best
+        opt, dat, keep = fit.opt, fit.dat, (fit.ua, fit.geno)
+        per_init = lib.mc_draws_per_init(C.byref(fit.opt), C.byref(fit.dat), K)
+        nnz, _ = data_counts(C.c_void_p(fit.mod.dev))
+        fit.close()
+    ts_obs = obs[K1][0] - obs[K0][0]
+    mle_q, mle_p = np.ascontiguousarray(obs[K0][1]), np.ascontiguousarray(obs[K0][2])
+    base = host.McRng()
+    lib.mc_srand(C.byref(base), SEED)
+    lib.mc_rng_jump(C.byref(base), 2 * n_init * per_init)     # the serial stream after the observed-data fits
+    mine = list(range(env.rank, n_rep, env.world))
+    env.barrier()
+    t0 = time.perf_counter()
+    rows = np.zeros((n_rep, 5))
+    for b in mine:
+        r = host.McReplicateResult()
+        rc = lib.mc_fit_replicate(C.byref(opt), C.byref(dat), env.local_rank, C.byref(base), b, K0, K1, n_init, K0,
+                                  mle_q.ctypes.data, mle_p.ctypes.data, C.byref(r))
+        if rc or r.fatal:
+            raise SystemExit("replicate %d: rc=%d fatal=%d" % (b, rc, r.fatal))
+        rows[b] = (r.ts, r.logL_H0, r.logL_HA, r.n_iter, 1.0)
+    flat = env.reduce(rows.ravel().tolist(), "SUM")         # the one exchange: disjoint rows
+    rows = np.array(flat).reshape(n_rep, 5)
+    env.barrier()
+    dt = time.perf_counter() - t0
+    dt = env.reduce([dt], "MAX")[0]
+    if not np.all(rows[:, 4] == 1.0):
+        raise SystemExit("a replicate was fitted %s times" % rows[:, 4].tolist())
+    total_iters = float(rows[:, 3].sum())
+    n_ge = int(np.sum(rows[:, 0] >= ts_obs))
+    del keep
+    return {
+        "value": total_iters / dt, "ms_per_step": dt * 1e3 / max(1, len(range(0, n_rep, env.world))), "steps": n_rep,
+        "config": {"workload": "c5: %s" % w["desc"], "I": w["I"], "L": w["L"], "T": T, "ploidy": w["ploidy"], "K": [K0, K1],
+                   "accel_scheme": 0, "replicates": n_rep, "replicate_to_rank": "b mod %d" % env.world, "n_init": n_init,
+                   "max_iter": budget, "step": "one bootstrap replicate",
+                   "timed": "device-side generation of every replicate + initialisation + em() of both models + the all-reduce",
+                   "time_to_finish_s": dt, "replicates_per_s": n_rep / dt, "em_iterations": total_iters,
+                   "ts_obs": ts_obs, "replicates_with_ts_ge_obs": n_ge, "p_value": n_ge / n_rep,
+                   "ts_first": rows[:8, 0].tolist(), "ts_checksum": float(rows[:, 0].sum()),
+                   "nonempty_cells_observed": nnz},
+    }
+
+
+# ------------------------------------------------------------------------------------------------ main
+def finish(env, args, out, scaling):
+    line = {"metric": "EM iterations/sec, IxLxK admixture", "value": out["value"], "unit": "EM iterations/s", "n_gpus": env.world,
+            "steps": out["steps"], "warmup": args.warmup, "ms_per_step": out["ms_per_step"], "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": out["config"]}
+    for k in ("roofline", "cpu_baseline", "secondary"):
+        if k in out:
+            line[k] = out[k]
+    print(json.dumps(line), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--accel", type=int, default=None, help="override the workload's acceleration scheme (0..6)")
+    ap.add_argument("--units", type=int, default=50, help="c4: random initialisations sharded over the GPUs")
+    ap.add_argument("--replicates", type=int, default=200, help="c5: bootstrap replicates sharded over the GPUs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra workloads carried on the default line (profiling "
+                    "runs: their kernels have the same names as the headline workload's)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args.gpus)                        # does not return
+
+    env = Env(args.gpus)
+    name = args.workload
+    w = WORKLOADS[name]
+    want_cpu = env.world == 1 and env.rank == 0 and not args.no_cpu_baseline
+
+    if name == "c5":
+        ua, geno = workload_data(w, env)
+        out = run_bootstrap(env, w, ua, geno, args.replicates, args.steps)
+        if want_cpu:
+            out["cpu_baseline"] = cpu_baseline(w, ua, geno, 0, args.cpu_budget, env.local_rank)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if env.rank == 0:
+            finish(env, args, out, "strong")
+        env.close()
+        return
+
+    ua, geno = workload_data(w, env)
+    T = int(ua.sum())
+    if name == "c4":
+        from multiclust_amd import host
+        accel = w["accel"] if args.accel is None else args.accel
+        fit = host.Fit(ua, geno, w["K"], device=env.local_rank, admixture=1, accel_scheme=accel, verbosity=1, abs_error=1e-300)
+        out = run_units(env, fit, w, T, args.units, args.steps, args.warmup)
+        fit.close()
+        if want_cpu:
+            out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget, env.local_rank)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if env.rank == 0:
+            finish(env, args, out, "strong")
+        env.close()
+        return
+
+    out, fit, accel = run_single_fit(args, env, name, ua, geno, args.steps, args.warmup)
+    if want_cpu:
+        out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget, env.local_rank)
+        out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    # the other BASELINE.json configurations on the same line (plain numbers, same measurement rules): configs[1] (c2) at
+    # N = 1; configs[3] (c4: 50 initialisations sharded) at every N; configs[4] (c5: 200 bootstrap replicates sharded) at N > 1
+    if name == "c3" and not args.no_secondary:
+        sec = {}
+        c4 = run_units(env, fit, WORKLOADS["c4"], T, args.units, args.steps, 0, with_roofline=False)
+        sec["c4"] = {k: c4[k] for k in ("value", "ms_per_step", "steps", "config")}
+        sec["c4"].update(unit="EM iterations/s", scaling="strong")
+        fit.close()
+        del geno
+        if env.world == 1:
+            w2 = WORKLOADS["c2"]
+            ua2, geno2 = workload_data(w2, env)
+            c2, fit2, _ = run_single_fit(args, env, "c2", ua2, geno2, 300, 5, with_roofline=False)
+            fit2.close()
+            sec["c2"] = dict(c2, unit="EM iterations/s")
+        else:
+            w5 = WORKLOADS["c5"]
+            ua5, geno5 = workload_data(w5, env)
+            c5 = run_bootstrap(env, w5, ua5, geno5, args.replicates, args.steps)
+            sec["c5"] = dict(c5, unit="EM iterations/s", scaling="strong")
+        out["secondary"] = sec
+    else:
+        fit.close()
+    if env.rank == 0:
+        finish(env, args, out, "weak")
+    env.close()
 
 
 if __name__ == "__main__":

@@ -59,6 +59,9 @@ int mchip_synchronize(mchip_context *ctx);
  */
 int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy,
 			const int32_t *uniquealleles, const uint8_t *geno);
+/* Counted on the device when a data set is installed: cells (i, l, m) with ILM[i][l][m] > 0 -- the cells the reference's E step
+ * visits (em_alg.c:338-342) and the unit the flop count of the path is stated in -- and non-missing allele copies. */
+int mchip_data_counts(mchip_context *ctx, uint64_t *nonempty_cells, uint64_t *allele_copies);
 /* the data set currently held, back in the upload form [I][L][ploidy] */
 int mchip_get_genotypes(mchip_context *ctx, uint8_t *geno);
 /*
@@ -135,7 +138,9 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
  * would report (its pindex: the accepted extrapolation, else the second EM iterate, else -- when the stopping rule fired
  * inside em_2_steps -- the cycle's starting iterate, accel_em.c:44-45); the other two slots are scratch.  Same arithmetic as
  * driving the cycle call by call (mchip_em_step, mchip_secant, mchip_loglik, mchip_step_dots, mchip_accel_update,
- * mchip_loglik_prefetch).  Admixture model with n_secants >= 1; otherwise MCHIP_ERR_UNSUPPORTED.
+ * mchip_loglik_prefetch).  Every model (admixture with individual or shared mixing proportions, mixture) with
+ * n_secants >= 1; MCHIP_ERR_UNSUPPORTED without a secant pair, or for an admixture data set with more than 32 alleles at a
+ * locus (the caller then drives the cycles call by call).
  */
 int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchip_run_state *state);
 

@@ -44,6 +44,7 @@ struct mchip_context {
 	uint8_t *d_col_allele;
 	uint8_t *d_gtA, *d_gtS, *d_gtC;
 	int count_bits, has_missing;
+	unsigned long long nnz_cells, n_copies;	/* cells with n_ic > 0, non-missing allele copies (mchip_data_counts) */
 	size_t geno_bytes_A, geno_bytes_S;
 	uint8_t *d_asA, *d_asS;		/* hard-partition scratch, allocated on first use */
 	uint8_t *d_initA, *d_initS;	/* genotype the hard-partition M step reads when it is not the data set itself (bootstrap) */
@@ -60,7 +61,7 @@ struct mchip_context {
 	double *d_stage;		/* K*T staging for the [K][T] <-> [T][K] transposes */
 	double *d_logp;			/* mixture model: log P table [T][K] */
 	/* workspaces */
-	int ichunk, n_ichunks, lchunk, n_lchunks, n_llpart, n_ll_col, n_ll_ind, flush_blocks, sparse;
+	int ichunk, n_ichunks, lchunk, n_lchunks, n_llpart, n_ll_col, n_ll_ind, flush_blocks, safe_rcp, sparse;
 	double *d_ssum;			/* [I][K] chunk-summed S-side sums */
 	double *d_Apart, *d_Spart, *d_llpart, *d_scalars;	/* d_scalars: [0]=logL, [1..3]=dots, [4..]=eta sums */
 	double *d_redpart;		/* block partials of the dot products / column sums */
@@ -326,6 +327,43 @@ __global__ void k_build_counts(const uint8_t *__restrict__ gtA, int I, int L, in
 		out[x / PERWORD] |= n << (BITS * (x % PERWORD));
 	}
 	gtC[idx] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+/* non-empty cells (i, c) with n_ic > 0 -- the unit SURVEY.md section 8d counts flops in -- and non-missing allele copies;
+ * thread = (block of 8 individuals, column) over gtA, block partial sums, one atomic per block */
+__global__ __launch_bounds__(256) void k_count_cells(const uint8_t *__restrict__ gtA, int I, int L, int pl, int T,
+		const int32_t *__restrict__ col_locus, const uint8_t *__restrict__ col_allele, unsigned long long *out)
+{
+	__shared__ unsigned red[2][256];
+	const size_t n = (size_t)((I + 7) / 8) * T, stride = (size_t)gridDim.x * 256;
+	unsigned cells = 0, copies = 0;
+	for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += stride) {
+		const int c = (int)(idx % T);
+		const size_t ib = idx / T;
+		const int l = col_locus[c];
+		const unsigned m = col_allele[c];
+		const uint8_t *src = gtA + (ib * L + l) * 8 * (size_t)pl;
+		for (int j = 0; j < 8; j++) {
+			unsigned cnt = 0;
+			for (int b = 0; b < pl; b++) cnt += (src[j * pl + b] == m);	/* padded individuals carry 0xFF */
+			cells += cnt != 0;
+			copies += cnt;
+		}
+	}
+	red[0][threadIdx.x] = cells;
+	red[1][threadIdx.x] = copies;
+	__syncthreads();
+	for (int w = 128; w > 0; w >>= 1) {
+		if ((int)threadIdx.x < w) {
+			red[0][threadIdx.x] += red[0][threadIdx.x + w];
+			red[1][threadIdx.x] += red[1][threadIdx.x + w];
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		atomicAdd(&out[0], (unsigned long long)red[0][0]);
+		atomicAdd(&out[1], (unsigned long long)red[1][0]);
+	}
 }
 
 /* host order [K][T] <-> device order [T][K] */
@@ -682,6 +720,7 @@ static mchip_pass_args pass_args(mchip_context *ctx, int slot)
 	a.P = ctx->d_p[slot]; a.Q = ctx->d_q[slot]; a.qstride = ctx->qstride;
 	a.ichunk = ctx->ichunk; a.n_ichunks = ctx->n_ichunks; a.Apart = ctx->d_Apart; a.llpart = ctx->d_llpart;
 	a.flush_blocks = ctx->flush_blocks;
+	a.safe_rcp = ctx->safe_rcp;
 	a.lchunk = ctx->lchunk; a.n_lchunks = ctx->n_lchunks; a.Spart = ctx->d_Spart;
 	a.asA = ctx->d_asA; a.asS = ctx->d_asS;
 	a.sparse = ctx->sparse; a.tile_cols = 8 * ctx->max_M;
@@ -837,6 +876,18 @@ static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
 		return fail(ctx, MCHIP_ERR_INVALID, "genotype allele index >= uniquealleles[l]%s", nullptr);
 	}
 	ctx->has_missing = (bad & 2) ? 1 : 0;
+	{	/* non-empty cells and allele copies of the data set (integer sums: order does not matter) */
+		unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(ctx->d_scalars + 60), h_cnt[2] = {0, 0};
+		HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
+		const size_t n = (size_t)((I + 7) / 8) * T;
+		hipLaunchKernelGGL(k_count_cells, dim3(nblk_capped(n) > 65536u ? 65536u : nblk_capped(n)), dim3(256), 0, ctx->stream, ctx->d_gtA, I, L,
+				   ploidy, T, ctx->d_col_locus, ctx->d_col_allele, d_cnt);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, ctx->stream));
+		HIPCHK(hipStreamSynchronize(ctx->stream));
+		ctx->nnz_cells = h_cnt[0];
+		ctx->n_copies = h_cnt[1];
+	}
 	/* packed per-column allele counts for the column pass */
 	ctx->count_bits = ploidy <= 3 ? 2 : (ploidy <= 15 ? 4 : 0);
 	if (getenv("MCHIP_NO_COUNTS")) ctx->count_bits = 0;
@@ -898,6 +949,15 @@ int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
 		dfree(ctx->d_initS);
 		return fail(ctx, MCHIP_ERR_INVALID, "init genotype allele index >= uniquealleles[l]%s", nullptr);
 	}
+	return MCHIP_OK;
+}
+
+int mchip_data_counts(mchip_context *ctx, uint64_t *nonempty_cells, uint64_t *allele_copies)
+{
+	if (!ctx) return MCHIP_ERR_INVALID;
+	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "no genotypes set%s", nullptr);
+	if (nonempty_cells) *nonempty_cells = ctx->nnz_cells;
+	if (allele_copies) *allele_copies = ctx->n_copies;
 	return MCHIP_OK;
 }
 
@@ -1019,6 +1079,16 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 			if (blocks > 1 << 16) blocks = 1 << 16;
 		}
 		ctx->flush_blocks = blocks;
+		/* Supported lower bounds (--bound): any value >= 0.  The fast kernels share one reciprocal among the four cells of a
+		 * column-pass step (1 / (t0 t1 t2 t3)) and between the two copies of a locus, which needs every t > 0 and
+		 * t^4 >= DBL_MIN: guaranteed when projection is on and p_lb >= 1e-75 (t >= p_lb).  Otherwise -- projection off
+		 * (--projection: an unobserved allele column, e.g. the phantom slot of a locus with missing data or an allele a
+		 * bootstrap replicate lacks, has P = 0 for every k, so t = 0 in its zero-count cells) or a smaller bound -- the
+		 * kernels take one reciprocal per non-empty cell and zero-count cells contribute exactly 0, as in em_alg.c:338-342.
+		 * A non-empty cell with t = 0 is NaN here as it is in the reference (n * 0 / 0). */
+		ctx->safe_rcp = (!do_projection || !(p_lb >= 1e-75)) ? 1 : 0;
+		if (getenv("MCHIP_FORCE_SAFE")) ctx->safe_rcp = 1;
+		if (ctx->safe_rcp) ctx->flush_blocks = 0;
 	}
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	return MCHIP_OK;
@@ -1108,8 +1178,9 @@ static int finalize_shared_eta(mchip_context *ctx, int to, const int *stop = nul
 }
 
 /* mixture model: E step (mode 0, optionally followed by the M step) or logL_mixture (mode 1) */
-static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int mode, const int *stop = nullptr)
+static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int mode, const int *stop = nullptr, int ll_slot = -1)
 {
+	if (ll_slot < 0) ll_slot = mode ? 1 : 0;	/* d_scalars entry that receives the log likelihood */
 	const size_t KT = (size_t)ctx->K * ctx->T;
 	hipLaunchKernelGGL(k_logp, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[from], ctx->d_logp, KT, mode == 0, stop);
 	mchip_pass_args a = pass_args(ctx, from);
@@ -1120,7 +1191,7 @@ static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int m
 	prof_mark(ctx, mode == 0 ? MCHIP_KERN_ACCUM_Q : MCHIP_KERN_LOGLIK, false);
 	const int nb = (ctx->I + MCHIP_BLOCK - 1) / MCHIP_BLOCK;
 	ctx->kt->mix_finalize(ctx->I, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[from], ctx->d_sik, ctx->d_llpart, mode, stop, ctx->stream);
-	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, nb, ctx->d_scalars + (mode ? 1 : 0), stop);
+	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, nb, ctx->d_scalars + ll_slot, stop);
 	if (do_mstep) {
 		int rc = finalize_shared_eta(ctx, to, stop);		/* em_alg.c:916-962 */
 		if (rc) return rc;
@@ -1587,7 +1658,9 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 	hipLaunchKernelGGL(k_diff, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[C], ctx->d_p[B], ctx->d_vp[0], KT, stop);
 	hipLaunchKernelGGL(k_diff, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[C], ctx->d_q[B], ctx->d_vq[0], nq, stop);
 	/* emll = log_likelihood(findex = C) -> d_scalars[1] (accel_em.c:53) */
-	{
+	if (!ctx->admixture) {
+		if ((rc = run_mixture(ctx, C, C, 0, 1, stop, 1))) return rc;	/* logL_mixture */
+	} else {
 		mchip_pass_args a = pass_args(ctx, C);
 		a.stop = stop;
 		prof_mark(ctx, MCHIP_KERN_LOGLIK, true);
@@ -1603,7 +1676,9 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 	hipLaunchKernelGGL(k_accel_update, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[A], ctx->d_up[0], ctx->d_vp[0], ctx->d_p[B], KT, 0.0, scheme == 4, ctx->d_scalars + 24, stop);
 	hipLaunchKernelGGL(k_accel_update, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[A], ctx->d_uq[0], ctx->d_vq[0], ctx->d_q[B], nq, 0.0, scheme == 4, ctx->d_scalars + 24, stop);
 	if ((rc = project_slot(ctx, B, stop))) return rc;
-	{
+	if (!ctx->admixture) {
+		if ((rc = run_mixture(ctx, B, B, 0, 1, stop, 2))) return rc;	/* nothing of this pass serves the next E step */
+	} else {
 		mchip_pass_args a = pass_args(ctx, B);
 		a.stop = stop;
 		prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
@@ -1624,13 +1699,13 @@ int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchi
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	if (!state || n_cycles < 1 || scheme < 1 || scheme > 4) return fail(ctx, MCHIP_ERR_INVALID, "accel_run: bad arguments%s", nullptr);
-	if (!ctx->admixture || !ctx->sparse || ctx->nsec < 1)
-		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "accel_run: admixture model, sparse path, one secant pair%s", nullptr);
+	if ((ctx->admixture && !ctx->sparse) || ctx->nsec < 1)
+		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "accel_run: needs a secant pair; loci with more than 32 alleles run cycle by cycle%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(ctx->d_run, state, sizeof *state, hipMemcpyHostToDevice, ctx->stream));
 	/* does Spart hold the S-side sums of this very slot (mchip_loglik_prefetch, or the accepted cycle that ended the
 	 * previous call)?  The first E step of the batch is told through the device flag the later cycles set themselves */
-	const int cyc0[4] = { 0, ctx->s_cache_slot == slot ? 1 : 0, 0, 0 };
+	const int cyc0[4] = { 0, (ctx->admixture && ctx->s_cache_slot == slot) ? 1 : 0, 0, 0 };
 	HIPCHK(hipMemcpyAsync(ctx->d_cyc, cyc0, sizeof cyc0, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));	/* cyc0 is a stack array */
 	ctx->s_cache_slot = -1;
@@ -1656,7 +1731,7 @@ int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchi
 	HIPCHK(hipMemcpyAsync(cyc_out, ctx->d_cyc, sizeof cyc_out, hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	/* a batch that ran to its end on an accepted cycle leaves that cycle's sums for whoever continues from this slot */
-	ctx->s_cache_slot = (!state->stopped && cyc_out[1]) ? slot : -1;
+	ctx->s_cache_slot = (ctx->admixture && !state->stopped && cyc_out[1]) ? slot : -1;
 	ctx->have_ll = 1;
 	return MCHIP_OK;
 }

@@ -89,13 +89,15 @@ int mchip_comm_create(mchip_comm **out, int n_devices, const int *devices)
 		delete c;
 		return MCHIP_ERR_HIP;
 	}
-	c->streams.resize(n_devices);
 	c->dbuf.assign(n_devices, nullptr);
+	c->streams.reserve(n_devices);
 	for (int d = 0; d < n_devices; d++) {
-		if (hipSetDevice(devices[d]) != hipSuccess || hipStreamCreateWithFlags(&c->streams[d], hipStreamNonBlocking) != hipSuccess) {
-			delete c;
+		hipStream_t st = nullptr;
+		if (hipSetDevice(devices[d]) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+			mchip_comm_destroy(c);	/* the communicators are initialised by now: destroy them, the streams made so far, RCCL's handle */
 			return MCHIP_ERR_HIP;
 		}
+		c->streams.push_back(st);
 	}
 	*out = c;
 	return MCHIP_OK;

@@ -46,6 +46,7 @@ struct mchip_pass_args {
 	double *Apart;		/* [n_ichunks][T][K] sum_i q_ik r_ic over the chunk */
 	double *llpart;		/* [gridDim.x*gridDim.y] block partial log-likelihoods */
 	int flush_blocks;	/* blocks of 8 individuals between log-product checks; 0 = check after every individual */
+	int safe_rcp;		/* 1: t may be 0 in zero-count cells or tiny (projection off, lower bound < 1e-75): no shared reciprocals */
 	/* individual pass (lane = individual, loop over a chunk of loci) */
 	int lchunk, n_lchunks;	/* loci per chunk (multiple of 8) */
 	double *Spart;		/* [n_lchunks][I][K] sum_c P_kc r_ic over the chunk */

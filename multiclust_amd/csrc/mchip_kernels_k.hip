@@ -198,7 +198,9 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_pass(mchip_pass_args a)
 #pragma unroll
 				for (int k = 1; k < K; k++) t = __builtin_fma(q[k], p[k], t);
 				if (ACCUM) {
-					const double r = (double)n * rcp_full(t);
+					/* a zero-count cell contributes exactly 0 whatever t is (em_alg.c:338-342): a column whose P is 0 for
+					 * every k (projection off) has t = 0 and 0 * (1/0) would be NaN */
+					const double r = n ? (double)n * rcp_full(t) : 0.0;
 #pragma unroll
 					for (int k = 0; k < K; k++) acc[k] = __builtin_fma(q[k], r, acc[k]);
 				}
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_pass(mchip_pass_args a)
  * n_ic = ILM[i][l][m] (BITS = 2 for ploidy <= 3, 4 for ploidy <= 15).  One coalesced 16-byte load per lane serves G
  * individuals and the count is a single v_bfe_u32, instead of two byte compares, a select and an add per cell.
  * MIX = false: admixture N-side sums  acc_k += q_ik * n / t;   MIX = true: mixture M step  acc_k += vik * n. */
-template <int BITS, bool MIX>
+template <int BITS, bool MIX, bool SAFE = false>
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a)
 {
 	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
@@ -294,7 +296,15 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 #pragma unroll
 						for (int k = 1; k < K; k++) t[j] = __builtin_fma(q[j][k], p[k], t[j]);
 					}
-					rcp_group(t, rc);
+					if (SAFE) {
+						/* projection off / tiny lower bounds (mchip_set_model): t may be 0 in a zero-count cell (a column
+						 * whose P is 0 for every k) and a product of four t's may underflow: one reciprocal per cell,
+						 * and none where n = 0, so such cells contribute exactly 0 as in em_alg.c:338-342 */
+#pragma unroll
+						for (int j = 0; j < NJ; j++) rc[j] = (n[j] != 0.0) ? rcp_full(t[j]) : 0.0;
+					} else {
+						rcp_group(t, rc);
+					}
 				}
 #pragma unroll
 				for (int j = 0; j < NJ; j++) {
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
 				double t = q[0] * pc[0];
 #pragma unroll
 				for (int k = 1; k < K; k++) t = __builtin_fma(q[k], pc[k], t);
-				const double r = (double)n * rcp_full(t);
+				const double r = n ? (double)n * rcp_full(t) : 0.0;	/* lanes that do not carry m: exactly 0, also when t = 0 */
 #pragma unroll
 				for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[k], r, acc[k]);
 			}
@@ -490,26 +500,37 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 					t[b] = q[0] * pc[b][0];
 #pragma unroll
 					for (int k = 1; k < K; k++) t[b] = __builtin_fma(q[k], pc[b][k], t[b]);
+					/* a missing copy borrowed column 0 of its locus; it takes t = 1 so that it leaves the log-product and
+					 * its partner's shared reciprocal alone, whatever column 0 holds (all zeros when projection is off and
+					 * a bootstrap replicate lacks that allele) */
+					if (!NOMISS) t[b] = miss[b] ? 1.0 : t[b];
 				}
 #pragma unroll
 				for (int b = 0; b < PL; b += 2) {
 					const double pp = t[b] * t[b + 1];
 					if (ACCUM) {
-						const double rp = rcp_full(pp);
-						const double r0 = miss[b] ? 0.0 : rp * t[b + 1];
-						const double r1 = miss[b + 1] ? 0.0 : rp * t[b];
+						double r0, r1;
+						if (SAFE) {	/* tiny lower bounds: the product of two t's may underflow */
+							r0 = miss[b] ? 0.0 : rcp_full(t[b]);
+							r1 = miss[b + 1] ? 0.0 : rcp_full(t[b + 1]);
+						} else {
+							const double rp = rcp_full(pp);
+							r0 = miss[b] ? 0.0 : rp * t[b + 1];
+							r1 = miss[b + 1] ? 0.0 : rp * t[b];
+						}
 #pragma unroll
 						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b][k], r0, acc[k]);
 #pragma unroll
 						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b + 1][k], r1, acc[k]);
 					}
-					if (NOMISS) {
-						prod *= pp;
+					if (SAFE) {
+						prod *= t[b];
+						rescale(prod, ex);
+						prod *= t[b + 1];
+						rescale(prod, ex);
 					} else {
-						prod *= miss[b] ? 1.0 : t[b];
-						prod *= miss[b + 1] ? 1.0 : t[b + 1];
+						prod *= pp;
 					}
-					if (SAFE) rescale(prod, ex);
 				}
 			} else {
 				for (int bb = 0; bb < pl; bb++) {	/* any other ploidy: one copy at a time */
@@ -882,6 +903,8 @@ inline dim3 indiv_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK - 1
  * the column pass also produces logL and the individual pass loops over every allele of every locus. */
 void launch_accum_p(const mchip_pass_args &a, hipStream_t s)
 {
+	if (a.sparse && a.count_bits == 2 && a.safe_rcp) { hipLaunchKernelGGL((k_column_counts<2, false, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
+	if (a.sparse && a.count_bits == 4 && a.safe_rcp) { hipLaunchKernelGGL((k_column_counts<4, false, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
 	if (a.sparse && a.count_bits == 2) { hipLaunchKernelGGL((k_column_counts<2, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
 	if (a.sparse && a.count_bits == 4) { hipLaunchKernelGGL((k_column_counts<4, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
 	if (a.sparse) {

@@ -63,6 +63,7 @@ def load():
         "mchip_mstep_from_partition": ([vp, vp, i32], i32),
         "mchip_mstep_from_rand_partition": ([vp, vp, i32], i32),
         "mchip_get_genotypes": ([vp, vp], i32),
+        "mchip_data_counts": ([vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], i32),
         "mchip_simulate_genotypes": ([vp, i32, i32, i32, vp, vp, i32, i32, vp, vp], i32),
         "mchip_set_init_genotypes": ([vp, vp], i32),
         "mchip_get_expected_counts": ([vp, vp], i32),
@@ -92,7 +93,7 @@ ABI_SYMBOLS = [
     "mchip_synchronize", "mchip_set_genotypes", "mchip_set_model", "mchip_set_p", "mchip_get_p", "mchip_set_q",
     "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_em_run", "mchip_accel_run", "mchip_last_loglik", "mchip_e_step",
     "mchip_loglik", "mchip_loglik_prefetch", "mchip_mstep_from_partition", "mchip_mstep_from_rand_partition",
-    "mchip_get_genotypes", "mchip_simulate_genotypes", "mchip_set_init_genotypes",
+    "mchip_get_genotypes", "mchip_data_counts", "mchip_simulate_genotypes", "mchip_set_init_genotypes",
     "mchip_get_expected_counts", "mchip_secant", "mchip_step_dots",
     "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
     "mchip_profile_end", "mchip_device_info", "mchip_comm_create", "mchip_comm_all_reduce", "mchip_comm_destroy",
@@ -133,6 +134,12 @@ class Context:
         I, L, p = geno.shape
         self._chk(self.lib.mchip_set_genotypes(self.h, I, L, p, ua.ctypes.data, geno.ctypes.data))
         self.I, self.L, self.ploidy, self.T = I, L, p, int(ua.sum())
+
+    def data_counts(self):
+        """(cells with n_ic > 0, non-missing allele copies) of the data set held, counted on the device"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.mchip_data_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def get_genotypes(self):
         g = np.empty((self.I, self.L, self.ploidy), dtype=np.uint8)

@@ -47,6 +47,11 @@ class McUnitResult(C.Structure):
                 ("seconds_run", C.c_double)]
 
 
+class McReplicateResult(C.Structure):
+    _fields_ = [("replicate", C.c_int), ("logL_H0", C.c_double), ("logL_HA", C.c_double), ("ts", C.c_double),
+                ("n_iter", C.c_int), ("fatal", C.c_int)]
+
+
 class McSummary(C.Structure):
     _fields_ = [("n_init", C.c_int), ("n_total_iter", C.c_int), ("n_max_iter", C.c_int),
                 ("n_maxll_times", C.c_int), ("n_maxll_init", C.c_int), ("ever_converged", C.c_int),
@@ -85,6 +90,10 @@ def load():
     lib.mc_accelerated_em_step.argtypes = [OP, DP, MP]
     lib.mc_log_likelihood.argtypes = [OP, DP, MP, C.c_int]
     lib.mc_log_likelihood.restype = C.c_double
+    lib.mc_step_size.argtypes = [OP, DP, MP]
+    lib.mc_step_size.restype = C.c_double
+    lib.mc_accelerated_update.argtypes = [OP, DP, MP, C.c_double]
+    lib.mc_accelerated_update.restype = C.c_double
     lib.mc_srand.argtypes = [C.POINTER(McRng), C.c_uint]
     lib.mc_rand.argtypes = [C.POINTER(McRng)]
     lib.mc_rng_jump.argtypes = [C.POINTER(McRng), C.c_uint64]
@@ -102,6 +111,8 @@ def load():
     lib.mc_simulation_begin.restype = None
     lib.mc_model_create_simulated.argtypes = [C.POINTER(MP), OP, DP, C.c_int, C.c_int, C.POINTER(McSimulation)]
     lib.mc_model_get_genotypes.argtypes = [MP, C.c_void_p]
+    lib.mc_fit_replicate.argtypes = [OP, DP, C.c_int, C.POINTER(McRng), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.POINTER(McReplicateResult)]
     lib.mc_aic.restype = C.c_double
     lib.mc_aic.argtypes = [C.c_double, C.c_int]
     lib.mc_bic.restype = C.c_double

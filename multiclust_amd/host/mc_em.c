@@ -708,7 +708,9 @@ void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod)
 		if (!mod->fatal) mod->logL = mc_log_likelihood(opt, dat, mod, mod->tindex);
 		return;
 	}
-	if (!opt->accel_scheme && opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
+	/* (with -i the warm-up loop and the do/while are two loops: when the first stops on the -T cap the second still runs
+	 * one more step, em_alg.c:61-88 -- the batched loop is a single loop, so it serves n_init_iter = 0 only) */
+	if (!opt->accel_scheme && opt->n_init_iter <= 0 && opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
 	    !getenv("MC_NO_BATCH") && em_batched(opt, mod) == 0)
 		return;
 	while (mod->n_iter < opt->n_init_iter && !stop)
@@ -719,7 +721,7 @@ void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod)
 	}
 	if (mod->converged || mod->fatal) return;
 	if (opt->accel_scheme >= MC_SQS1 && opt->accel_scheme <= MC_QN && opt->q == 1 && !opt->adjust_step && !stop &&
-	    opt->admixture && opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
+	    opt->verbosity <= MC_MINIMAL && !opt->n_seconds &&
 	    !getenv("MC_NO_BATCH") && em_accel_batched(opt, mod) == 0)
 		return;
 	do {

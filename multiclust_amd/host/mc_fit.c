@@ -122,3 +122,45 @@ int mc_fit_unit(const mc_options *opt, const mc_data *dat, mc_model *mod, unsign
 	out->seconds_run = mod->seconds_run;
 	return 0;
 }
+
+/* One parametric-bootstrap replicate, the unit run_bootstrap shards (multiclust.c:675-708): data set b is generated on
+ * `device` from the H0 fit (mle_K clusters, mle_q, mle_p) at the position replicate b has in the serial rand() stream
+ * (`base` = the stream where the first replicate begins), then n_init initialisations of the null_K model and of the alt_K
+ * model are fitted to it (only one when K = 1, multiclust.c:630), each from the stream where the serial program would be;
+ * the test statistic is the difference of the two best log likelihoods. */
+int mc_fit_replicate(const mc_options *opt, const mc_data *dat, int device, const mc_rng *base, int b, int null_K, int alt_K,
+		     int n_init, int mle_K, const double *mle_q, const double *mle_p, mc_replicate_result *out)
+{
+	const uint64_t per_init = mc_draws_per_init(opt, dat, alt_K);
+	const uint64_t units0 = null_K == 1 ? 1 : (uint64_t)n_init, units1 = alt_K == 1 ? 1 : (uint64_t)n_init;
+	const uint64_t per_replicate = mc_bootstrap_draws(opt, dat) + (units0 + units1) * per_init;
+	mc_rng rng = *base;
+	mc_simulation gen;
+	int rc = 0;
+	if (!opt->admixture) return MCHIP_ERR_UNSUPPORTED;	/* the mixture model's replicate is drawn on the host */
+	memset(out, 0, sizeof *out);
+	out->replicate = b;
+	mc_rng_jump(&rng, (uint64_t)b * per_replicate);
+	mc_simulation_begin(&gen, opt, dat, mle_K, mle_q, mle_p, &rng);
+	for (int h = 0; h < 2 && !rc; h++) {
+		const int K = h ? alt_K : null_K;
+		const uint64_t units = h ? units1 : units0;
+		double best = -INFINITY;
+		mc_model *mod = NULL;
+		if ((rc = mc_model_create_simulated(&mod, opt, dat, K, device, &gen))) break;
+		for (uint64_t u = 0; u < units; u++) {
+			const int delta_keep = mod->delta_index;
+			mc_reset_model_state(mod);
+			mod->delta_index = delta_keep;
+			if ((rc = mc_initialize_model(opt, dat, mod, &rng))) break;
+			mc_em(opt, dat, mod);
+			out->n_iter += mod->n_iter;
+			if (mod->fatal) { out->fatal = mod->fatal; break; }
+			if (mod->logL > best) best = mod->logL;
+		}
+		mc_model_free(mod);
+		if (h) out->logL_HA = best; else out->logL_H0 = best;
+	}
+	out->ts = out->logL_HA - out->logL_H0;
+	return rc;
+}

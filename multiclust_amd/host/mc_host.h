@@ -150,6 +150,17 @@ uint64_t mc_draws_per_init(const mc_options *opt, const mc_data *dat, int K);
 /* initialisation `unit` of a run seeded with `seed`: jump the stream to unit * draws_per_init, initialise, em() */
 int mc_fit_unit(const mc_options *opt, const mc_data *dat, mc_model *mod, unsigned int seed, int unit, mc_unit_result *out);
 
+
+/* ---- one bootstrap replicate: the other unit of sharding (run_bootstrap, multiclust.c:675-708) ---- */
+typedef struct mc_replicate_result {
+	int replicate;
+	double logL_H0, logL_HA, ts;	/* best log likelihood of the null_K and alt_K fits, and their difference */
+	int n_iter;			/* EM iterations of all fits of the replicate */
+	int fatal;
+} mc_replicate_result;
+int mc_fit_replicate(const mc_options *opt, const mc_data *dat, int device, const mc_rng *base, int b, int null_K, int alt_K,
+		     int n_init, int mle_K, const double *mle_q, const double *mle_p, mc_replicate_result *out);
+
 #ifdef __cplusplus
 }
 #endif

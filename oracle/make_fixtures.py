@@ -7,7 +7,7 @@ fixed Python `random` seed, (2) runs the reference-linked harness (oracle/ref_ha
 dumps inputs and the reference's outputs at full precision.  Fixtures are data only (inputs + expected
 outputs); no reference source is copied.  Re-run: `python oracle/make_fixtures.py`.
 """
-import os, random, shutil, subprocess, sys
+import json, os, random, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -64,6 +64,11 @@ def write_c1(path):
 
 
 BOOTSTRAP_CASES = ("multi_admix_k4", "tetra_admix_k3", "missing_admix_k3", "multi_mix_k3", "multi_admix_c_k3")
+# section 6b as well: EM steps on the simulated data set (projection off: alleles the replicate lacks keep p = 0)
+BOOTSTRAP_EM_CASES = ("multi_admix_k4_noproj", "rare_admix_k3_noproj", "rare_admix_k3_bs")
+# section 7: Rand-EM initialisation with this many candidates
+RANDEM_CASES = {"multi_admix_k3_randem": 6, "wide_admix_k2_randem": 5, "tetra_admix_k3_randem": 4,
+                "missing_admix_k2_randem": 5, "multi_admix_c_k3_randem": 4, "multi_mix_k3_randem": 5}
 
 
 def run(name, stru, n_em, snaps, n_cycles, args, keep_ilm=True):
@@ -75,7 +80,13 @@ def run(name, stru, n_em, snaps, n_cycles, args, keep_ilm=True):
     env = dict(os.environ)
     if name in BOOTSTRAP_CASES:     # section 6 of the harness: one parametric-bootstrap data set (bs_ilm.u8)
         env["REF_HARNESS_BOOTSTRAP"] = "1"
+    if name in BOOTSTRAP_EM_CASES:
+        env["REF_HARNESS_BOOTSTRAP"] = "2"
+    if name in RANDEM_CASES:
+        env["REF_HARNESS_RANDEM"] = str(RANDEM_CASES[name])
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, cwd=out, env=env)
+    with open(os.path.join(out, "manifest.json")) as f:
+        json.load(f)                # the reference exit(0)s on NaN / decrease: a truncated manifest is a failed fixture
     with open(os.path.join(out, "ARGS.txt"), "w") as f:
         f.write(" ".join(["-f", os.path.basename(stru)] + args) + "\n")
     if not keep_ilm:
@@ -155,6 +166,43 @@ def main():
     run("c1_admix_k3_tight", c1, 1, "1", 0, ["-a", "-k", "3", "-r", "1234567", "-E", "1e-10"], keep_ilm=False)
     run("multi_admix_k4_tight", multi, 1, "1", 0, ["-a", "-k", "4", "-r", "7", "-E", "1e-10"], keep_ilm=False)
 
+    # (no -s with --projection: an extrapolated point is not projected back then, its log likelihood is NaN and the
+    # reference's stop() calls exit(0), em_alg.c:106-110)
+    # projection off (--projection): unobserved allele columns keep p = 0 for every k -- the phantom slot of loci with
+    # missing data, and alleles a bootstrap replicate lacks (rare.stru has many singleton alleles)
+    rare = os.path.join(data, "rare.stru")
+    rnd2 = random.Random(123)
+    write_stru(rare, 24, 70, 3, 2, [rnd2.choice([3, 4, 5, 6]) for _ in range(70)], seed=5)
+    run("missing_admix_k3_noproj", miss, 20, "1,2,3,20", 3, ["-a", "-k", "3", "-r", "5", "--projection"])
+    run("multi_admix_k4_noproj", multi, 10, "1,3,10", 3, ["-a", "-k", "4", "-r", "7", "--projection"])
+    run("rare_admix_k3_noproj", rare, 10, "1,3,10", 3, ["-a", "-k", "3", "-r", "9", "--projection"])
+    run("rare_admix_k3_bs", rare, 3, "1,3", 0, ["-a", "-k", "3", "-r", "9"])
+    run("tetra_admix_k3_noproj", tetra, 10, "1,3,10", 3, ["-p", "4", "-a", "-k", "3", "-r", "11", "--projection"])
+    # a lower bound far below the default (--bound): t^4 underflows in the shared-reciprocal kernels
+    run("multi_admix_k4_tinybound", multi, 10, "1,3,10", 3, ["-a", "-k", "4", "-r", "7", "-s", "3", "--bound", "1e-120"])
+    # mixture model with enough loci that exp(max_k v_ik) underflows: logL_mixture's scaling branch
+    # (log_likelihood.c:209-224) is executed by the reference here
+    mixlong = os.path.join(data, "mixlong.stru")
+    write_stru(mixlong, 36, 1800, 3, 2, [2] * 1800, seed=8)
+    run("mixlong_mix_k3", mixlong, 6, "1,2,6", 3, ["-k", "3", "-r", "5", "-s", "3"], keep_ilm=False)
+    run("mixlong_mix_k3_s1", mixlong, 2, "1,2", 3, ["-k", "3", "-r", "5", "-s", "1"], keep_ilm=False)
+    # mixture model that converges slowly enough for several accelerated cycles (few loci: soft assignments)
+    mixslow = os.path.join(data, "mixslow.stru")
+    rnd4 = random.Random(11)
+    write_stru(mixslow, 120, 8, 3, 2, [rnd4.choice([2, 3]) for _ in range(8)], seed=11)
+    for sch, tag in ((1, "s1"), (2, "s2"), (3, "s3"), (4, "qn1"), (5, "qn2"), (6, "qn3")):
+        run("mixslow_mix_k3_" + tag, mixslow, 3, "1,3", 2, ["-k", "3", "-r", "5", "-s", str(sch)], keep_ilm=False)
+    # Rand-EM initialisation (harness section 7; the reference's command line cannot select it)
+    wide = os.path.join(data, "wide.stru")
+    rnd3 = random.Random(321)
+    write_stru(wide, 30, 40, 2, 2, [rnd3.choice([2, 3, 4, 5, 6]) for _ in range(40)], seed=6)
+    run("multi_admix_k3_randem", multi, 2, "1,2", 0, ["-a", "-k", "3", "-r", "7"])
+    run("wide_admix_k2_randem", wide, 2, "1,2", 0, ["-a", "-k", "2", "-r", "3"])
+    run("tetra_admix_k3_randem", tetra, 2, "1,2", 0, ["-p", "4", "-a", "-k", "3", "-r", "11"])
+    run("missing_admix_k2_randem", miss, 2, "1,2", 0, ["-a", "-k", "2", "-r", "5"])
+    run("multi_admix_c_k3_randem", multi, 2, "1,2", 0, ["-a", "-c", "-k", "3", "-r", "5"])
+    run("multi_mix_k3_randem", multi, 2, "1,2", 0, ["-k", "3", "-r", "5"])
+
     # reader-only fixtures: interleaved layout + "-1" line; remapped missing code
     inter = os.path.join(data, "multi_interleaved.stru")
     write_interleaved(multi, inter, 2)
@@ -176,6 +224,12 @@ def main():
     run_cli("multi_admix_c_k3", multi, ["-a", "-c", "-k", "3", "-r", "5", "-n", "2"])
     # (a K range, -1 <a> -2 <b>, aborts inside the reference itself after the first K: "free(): invalid pointer")
     run_cli("tetra_admix_k3", tetra, ["-p", "4", "-a", "-k", "3", "-r", "11", "-n", "2"])
+    # -i beyond where the warm-up loop stops: on convergence em() returns (em_alg.c:73-74); on the -T cap it still enters
+    # its do/while, i.e. one more EM step / accelerated cycle (em_alg.c:61-88)
+    run_cli("multi_admix_k4_i1000", multi, ["-a", "-k", "4", "-r", "7", "-n", "2", "-i", "1000"])
+    run_cli("multi_admix_k4_i1000_T5", multi, ["-a", "-k", "4", "-r", "7", "-n", "2", "-i", "1000", "-T", "5"])
+    run_cli("multi_admix_k4_i1000_T5_s3", multi, ["-a", "-k", "4", "-r", "7", "-n", "2", "-i", "1000", "-T", "5", "-s", "3"])
+    run_cli("missing_admix_k3_noproj", miss, ["-a", "-k", "3", "-r", "5", "-n", "2", "--projection"])
 
 
 if __name__ == "__main__":

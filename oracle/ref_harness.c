@@ -33,6 +33,11 @@ double accelerated_update(options *opt, data *dat, model *mod, double s);
 double qn_accelerated_update(options *opt, data *dat, model *mod);
 void michelot_project(double *, int, double, double);
 int maximize_likelihood(options *opt, data *dat, model *mod, int bootstrap);
+void random_allele_center(data *dat, model *mod);
+void random_individual_center(data *dat, model *mod);
+void random_individual_partition(data *dat, model *mod);
+void initialize_parameters_admixture(options *opt, data *dat, model *mod);
+void initialize_parameters_mixture(data *dat, model *mod);
 
 static const char *outdir;
 static FILE *man;
@@ -474,10 +479,93 @@ int main(int argc, const char **argv)
 			dump_p("p_bsinit.f64", dat, mod, 0);
 			mod->mle_pKLM = alias; mod->mle_etaik = eta_alias; mod->mle_etak = etak_alias;
 		}
+		/* 6b: what run_bootstrap's fits do next: EM steps on the simulated data set from that initialisation.  With
+		 * --projection (do_projection = 0) an allele the replicate lacks keeps p = 0 for every k. */
+		if (atoi(getenv("REF_HARNESS_BOOTSTRAP")) >= 2) {
+			const int n_bs = 5;
+			double saved_abs = opt->abs_error;
+			int absent = 0;
+			for (int l = 0; l < dat->L; l++)
+				for (int m = 0; m < dat->uniquealleles[l]; m++) {
+					int tot = 0;
+					for (int i = 0; i < dat->I; i++) tot += dat->ILM[i][l][m];
+					if (!tot) absent++;
+				}
+			man_int("bs_absent_columns", absent);
+			opt->abs_error = 0; opt->rel_error = 0;
+			f = xopen("bs_em_ll.f64");
+			for (int s = 1; s <= n_bs; s++) {
+				em_step(opt, dat, mod);
+				double ll = mod->logL;
+				fwrite(&ll, sizeof ll, 1, f);
+			}
+			fclose(f);
+			opt->abs_error = saved_abs;
+			dump_q("q_bsstep.f64", opt, dat, mod, 0);
+			dump_p("p_bsstep.f64", dat, mod, 0);
+			dump_sik("sik_bsstep.f64", opt, dat, mod);
+			man_int("bs_em_steps", n_bs);
+			man_dbl("bs_ll_after_em", log_likelihood(opt, dat, mod, 0));
+		}
 		cleanup_parametric_bootstrap(dat);
 		free(mod->mle_pKLM);
 		mod->mle_pKLM = NULL; mod->mle_etaik = NULL; mod->mle_etak = NULL;
 		man_int("bootstrap_seed", (long)opt->seed + 7);
+	}
+
+	/* ---- section 7: Rand-EM initialisation (rnd_init.c:123-160, 412-444), unreachable from the reference's own command
+	 * line (initialization_procedure is never set to RAND_EM): REF_HARNESS_RANDEM=<n candidates>.  7a repeats the calls of
+	 * randem_initialize_*() with recording (per-candidate log likelihood, first candidate's parameters); 7b is the
+	 * reference's own routine through initialize_model(), then em() from its result.  Both must agree. ---- */
+	if (getenv("REF_HARNESS_RANDEM") && mod->K > 1) {
+		const int n_cand = atoi(getenv("REF_HARNESS_RANDEM"));
+		double max_ll = -INFINITY;
+		int best = -1;
+		opt->accel_scheme = 0;
+		opt->q = 1;
+		opt->n_rand_em_init = n_cand;
+		reset_model_state(opt, mod);
+		f = xopen("randem_ll.f64");
+		for (int c = 0; c < n_cand; c++) {
+			if (opt->admixture) {
+				random_allele_center(dat, mod);
+				initialize_parameters_admixture(opt, dat, mod);
+			} else {
+				if (opt->initialization_method == RANDOM_PARTITION) random_individual_partition(dat, mod);
+				else random_individual_center(dat, mod);
+				initialize_parameters_mixture(dat, mod);
+			}
+			if (c == 0) {
+				dump_q("q_randem_c0.f64", opt, dat, mod, 0);
+				dump_p("p_randem_c0.f64", dat, mod, 0);
+			}
+			double ll = em_e_step(opt, dat, mod);
+			fwrite(&ll, sizeof ll, 1, f);
+			if (ll > max_ll) { max_ll = ll; best = c; }
+		}
+		fclose(f);
+		man_int("randem_candidates", n_cand);
+		man_int("randem_best", best);
+		man_key("rand_after_randem_trace"); fprintf(man, "%d", rand());
+		opt->initialization_procedure = RAND_EM;
+		reset_model_state(opt, mod);
+		if ((err = initialize_model(opt, dat, mod))) die("initialize_model (Rand-EM) failed");
+		man_key("rand_after_randem"); fprintf(man, "%d", rand());
+		dump_q("q_randem.f64", opt, dat, mod, 0);
+		dump_p("p_randem.f64", dat, mod, 0);
+		{	/* the winner's parameters are those of a candidate: its log likelihood after one EM step must be the recorded maximum */
+			double ll = em_e_step(opt, dat, mod);
+			if (ll != max_ll) die("Rand-EM: traced candidates disagree with randem_initialize_*()");
+		}
+		reset_model_state(opt, mod);
+		initialize_model(opt, dat, mod);
+		em(opt, dat, mod);
+		man_int("randem_run_n_iter", mod->n_iter);
+		man_int("randem_run_converged", mod->converged);
+		man_dbl("randem_run_logL", mod->logL); man_hex("randem_run_logL_hex", mod->logL);
+		dump_q("q_randemrun.f64", opt, dat, mod, mod->pindex);
+		dump_p("p_randemrun.f64", dat, mod, mod->pindex);
+		opt->initialization_procedure = NOTHING;
 	}
 
 	fprintf(man, "\n}\n");

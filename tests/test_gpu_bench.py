@@ -1,0 +1,71 @@
+"""-m gpu: the sharded workloads of bench.py (c4: initialisations u mod N; c5: bootstrap replicates b mod N) on small data
+sets, against the drop-in command line run on the same file with the same seed: per-unit log likelihoods and per-replicate
+test statistics must agree (the command line prints them with six decimals)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from golden_util import GOLD, Golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "multiclust_amd", "bin", "multiclust")
+sys.path.insert(0, ROOT)
+
+
+class OneRank:
+    """bench.Env for a single rank without a process group"""
+    world, rank, local_rank, dist, cdev = 1, 0, 0, None, "cpu"
+
+    def barrier(self, ctx=None):
+        pass
+
+    def reduce(self, values, op):
+        return list(values)
+
+
+def test_c4_units_agree_with_command_line(tmp_path):
+    import bench
+    from multiclust_amd import host
+    g = Golden("multi_admix_k4")
+    n_units, cycles = 6, 8
+    res = subprocess.run([BIN, "-f", os.path.join(GOLD, "data", "multi.stru"), "-d", str(tmp_path), "-a", "-k", "4", "-n", str(n_units),
+                          "-s", "3", "-T", str(2 * cycles - 1), "-r", str(bench.SEED)],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    cli = [(float(m.group(1)), int(m.group(2))) for m in
+           re.finditer(r"initialization = \d+: (-?\d+\.\d+) \(.*?\) in\s+(\d+) iterations", res.stdout)]
+    assert len(cli) == n_units
+    fit = host.Fit(g.ua, g.geno, 4, admixture=1, accel_scheme=3, verbosity=1, abs_error=1e-300)
+    w = dict(I=g.I, L=g.L, ploidy=g.ploidy, K=4, desc="multi.stru")
+    out = bench.run_units(OneRank(), fit, w, g.T, n_units, cycles, 1, with_roofline=False)
+    fit.close()
+    cfg = out["config"]
+    assert cfg["units"] == n_units and len(cfg["unit_logL"]) == n_units
+    assert cfg["em_iterations"] == sum(n for _, n in cli) == n_units * 2 * cycles
+    for (ll, _), got in zip(cli, cfg["unit_logL"]):
+        assert abs(ll - got) <= 1e-6, (ll, got)
+    assert abs(cfg["best_logL"] - max(ll for ll, _ in cli)) <= 1e-6
+
+
+def test_c5_replicates_agree_with_command_line(tmp_path):
+    import bench
+    g = Golden("tetra_admix_k3")
+    n_rep, budget = 4, 9
+    res = subprocess.run([BIN, "-f", os.path.join(GOLD, "data", "tetra.stru"), "-d", str(tmp_path), "-p", "4", "-a", "-k", "3", "-n", "1",
+                          "-b", str(n_rep), "-T", str(budget), "-r", str(bench.SEED)],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    cli = [(float(a), float(b)) for a, b in re.findall(r"test statistics bs=(-?\d+\.\d+) obs=(-?\d+\.\d+)", res.stdout)]
+    assert len(cli) == n_rep
+    w = dict(I=g.I, L=g.L, ploidy=4, K=3, desc="tetra.stru")
+    out = bench.run_bootstrap(OneRank(), w, g.ua, g.geno, n_rep, budget, n_init=1)
+    cfg = out["config"]
+    assert cfg["replicates"] == n_rep and cfg["em_iterations"] == n_rep * 2 * (budget + 1)
+    assert abs(cfg["ts_obs"] - cli[0][1]) <= 2e-6
+    for (bs, _), got in zip(cli, cfg["ts_first"]):
+        assert abs(bs - got) <= 2e-6, (bs, got)

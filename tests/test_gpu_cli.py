@@ -55,6 +55,10 @@ def compare_file(ref, got, atol):
     ("multi_admix_c_k3", 2e-6),
     ("tetra_admix_k3", 2e-6),
     ("missing_admix_k3_s3", 5e-3),       # SQUAREM: the path may differ through accept ties; converged fit within tolerance
+    ("multi_admix_k4_i1000", 2e-6),      # -i beyond convergence: em() returns from the warm-up loop (em_alg.c:73-74)
+    ("multi_admix_k4_i1000_T5", 2e-6),   # -i beyond the -T cap: one more EM step in the do/while (7 iterations, not 6)
+    ("multi_admix_k4_i1000_T5_s3", 2e-6),  # ... one accelerated cycle that stops inside em_2_steps
+    ("missing_admix_k3_noproj", 2e-6),   # --projection: the phantom allele slots of loci with missing data keep p = 0
 ])
 def test_cli_matches_reference_binary(case, atol, tmp_path):
     gdir, out = run_cli(case, tmp_path)

@@ -102,6 +102,155 @@ def test_config3_full_size_properties_and_slice_against_oracle():
     ctx.close()
 
 
+def columns_of(ua, loci):
+    off = np.concatenate([[0], np.cumsum(ua)])
+    return np.concatenate([np.arange(off[l], off[l + 1]) for l in loci])
+
+
+def check_step_and_cycle_on_slices(ctx, ua, geno, K, lb, q0, p0):
+    """One EM step and one SQUAREM-3 cycle at full size, checked where the oracle finishes in seconds:
+      * S_ik and q'_i of an individual depend on its own genotype, q_i and P: oracle on a slice of individuals;
+      * p'_kl. of a locus depends on every individual's genotype at that locus, Q and p_.l.: oracle on a slice of loci
+        with ALL individuals (the N-side sums of em_alg.c:706-752);
+      * the cycle (accel_em.c:35-114): u, v, the three dot products and the step from numpy on the downloaded iterates, the
+        extrapolated point x0 - 2 s u + s^2 (v - u) elementwise, its projection by the oracle's michelot_project on the
+        same slices; log likelihoods by the halves identity."""
+    I, L, pl = geno.shape
+    rs = np.random.default_rng(11)
+    sel_i = np.unique(np.concatenate([[0, 1, I // 2 - 1, I // 2, I - 2, I - 1], rs.integers(0, I, 10)]))
+    sel_l = np.unique(np.concatenate([[0, 1, 7, 8, L // 2, L - 9, L - 8, L - 1], rs.integers(0, L, 24)]))
+    cols = columns_of(ua, sel_l)
+    ctx.set_q(0, q0)
+    ctx.set_p(0, p0)
+    ll0 = ctx.em_step(0, 1)
+    sik = ctx.expected_counts()
+    np.testing.assert_allclose(sik.sum(axis=1), float(pl) * L, rtol=1e-13)
+    q1, p1 = ctx.get_q(1), ctx.get_p(1)
+    opt = ob.make_options(lower_bound=lb, fused=1, abs_error=0.0)
+    mod_i = ob.Model(ob.Data(len(sel_i), L, pl, ua, geno[sel_i]), opt, K)
+    mod_i.q(0)[...] = q0[sel_i]
+    mod_i.p(0)[...] = p0
+    mod_i.em_step()
+    np.testing.assert_allclose(sik[sel_i], mod_i.sik(), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(q1[sel_i], mod_i.q(0), rtol=1e-10, atol=1e-14)
+    mod_l = ob.Model(ob.Data(I, len(sel_l), pl, ua[sel_l], np.ascontiguousarray(geno[:, sel_l])), opt, K)
+    mod_l.q(0)[...] = q0
+    mod_l.p(0)[...] = p0[:, cols]
+    mod_l.em_step()
+    np.testing.assert_allclose(p1[:, cols], mod_l.p(0), rtol=1e-10, atol=1e-14)
+    check_simplex(q1, p1, ua, lb)
+    assert ctx.loglik(0) == ll0
+    # second EM step, secants, step size
+    ll1 = ctx.em_step(1, 2)
+    assert ll1 > ll0
+    q2, p2 = ctx.get_q(2), ctx.get_p(2)
+    mod_i.q(0)[...] = q1[sel_i]                                       # the slice's own M step saw only its individuals: the
+    mod_i.p(0)[...] = p1                                              # second step starts from the full p' (ours, checked above)
+    mod_i.em_step()
+    np.testing.assert_allclose(q2[sel_i], mod_i.q(0), rtol=1e-10, atol=1e-14)
+    mod_l.q(0)[...] = q1
+    mod_l.p(0)[...] = p1[:, cols]
+    mod_l.em_step()
+    np.testing.assert_allclose(p2[:, cols], mod_l.p(0), rtol=1e-10, atol=1e-14)
+    ctx.secant(0, 0, 1, 0)
+    ctx.secant(1, 0, 2, 1)
+    d = ctx.step_dots(0)
+    uq, up, vq, vp = q1 - q0, p1 - p0, q2 - q1, p2 - p1
+    utu = float((uq * uq).sum() + (up * up).sum())
+    utvu = float((uq * (vq - uq)).sum() + (up * (vp - up)).sum())
+    vutvu = float(((vq - uq) ** 2).sum() + ((vp - up) ** 2).sum())
+    np.testing.assert_allclose(d, [utu, utvu, vutvu], rtol=1e-9)
+    s = -np.sqrt(d[0] / d[2])                                          # SQUAREM S3 (accel_em.c:227-229), clamp 236-237
+    if s > -1:
+        s = -1.0
+    ctx.accel_update(1, 0, 0, s, 0)                                    # slot 1 := projected extrapolation
+    qx, px = ctx.get_q(1), ctx.get_p(1)
+    want_q = q0 - 2 * s * uq + s * s * (vq - uq)
+    want_p = p0 - 2 * s * up + s * s * (vp - up)
+    for i in sel_i:
+        np.testing.assert_allclose(qx[i], ob.michelot(want_q[i], lb), rtol=1e-12, atol=1e-16)
+    off = np.concatenate([[0], np.cumsum(ua)])
+    for l in sel_l:
+        for k in range(K):
+            np.testing.assert_allclose(px[k, off[l]:off[l + 1]], ob.michelot(want_p[k, off[l]:off[l + 1]], lb), rtol=1e-12, atol=1e-16)
+    check_simplex(qx, px, ua, lb)
+    llx = ctx.loglik_prefetch(1)
+    assert llx == ctx.loglik(1)
+    return qx, px, llx
+
+
+def test_config3_pside_and_squarem_cycle_on_slices():
+    I, L, K = 10000, 100000, 8
+    ua, geno = fast_geno(I, L, 2, 4, seed=20250121)
+    lb = ob.lib.mco_lower_bound(1e-8, I, 2)
+    q0, p0 = random_params(I, ua, K, seed=6, lower_bound=lb)
+    ctx = mc.Context(0)
+    ctx.set_genotypes(ua, geno)
+    assert ctx.data_counts()[1] == I * L * 2
+    ctx.set_model(K, lower_bound=lb, n_secants=1)
+    qx, px, llx = check_step_and_cycle_on_slices(ctx, ua, geno, K, lb, q0, p0)
+    ctx.close()
+    halves = []
+    for sl in (slice(0, I // 2), slice(I // 2, I)):                    # log likelihood of the extrapolated point: halves identity
+        c = mc.Context(0)
+        c.set_genotypes(ua, geno[sl])
+        c.set_model(K, lower_bound=lb)
+        c.set_q(0, qx[sl])
+        c.set_p(0, px)
+        halves.append(c.loglik(0))
+        c.close()
+    assert abs(sum(halves) - llx) <= 1e-11 * abs(llx)
+
+
+@pytest.mark.parametrize("K", [7, 8])
+def test_config5_full_size_tetraploid(K):
+    """BASELINE.json configs[4]: 5 000 tetraploid x 50 000 loci, K = 7 and 8 (the two models of -b 200 -k 8): the 4-bit
+    packed column pass and the tetraploid sparse pass at size; then one parametric-bootstrap data set of that size
+    generated on the device from the fitted point, byte for byte against the host generator (bootstrap.c:84-124) on the
+    first and the last individuals."""
+    import ctypes as C
+    from multiclust_amd import host
+    I, L, pl = 5000, 50000, 4
+    ua, geno = fast_geno(I, L, pl, 4, seed=20250122 + K)
+    lb = ob.lib.mco_lower_bound(1e-8, I, pl)
+    q0, p0 = random_params(I, ua, K, seed=7, lower_bound=lb)
+    ctx = mc.Context(0)
+    ctx.set_genotypes(ua, geno)
+    cells, copies = ctx.data_counts()
+    assert copies == I * L * pl and I * L <= cells <= copies
+    ctx.set_model(K, lower_bound=lb, n_secants=1)
+    qx, px, llx = check_step_and_cycle_on_slices(ctx, ua, geno, K, lb, q0, p0)
+    # bootstrap data set from (qx, px)
+    hl = host.load()
+    opt = host.McOptions()
+    hl.mc_make_options(C.byref(opt))
+    opt.admixture = 1
+    rng = host.McRng()
+    hl.mc_srand(C.byref(rng), 777)
+    window = np.array([rng.r[(rng.f + t) % 31] for t in range(31)], dtype=np.int64).astype(np.uint32)
+    ctx.simulate_genotypes(I, L, pl, ua, window, K, qx, px)
+    sim = ctx.get_genotypes()
+    assert sim.shape == (I, L, pl) and np.all(sim < ua[None, :, None])
+    ua32 = np.ascontiguousarray(ua, dtype=np.int32)
+    n = 3
+    for first in (0, I - n):
+        r2 = host.McRng.from_buffer_copy(rng)
+        hl.mc_rng_jump(C.byref(r2), 2 * first * L * pl)                # two draws per allele copy (bootstrap.c:95-120)
+        part = np.empty((n, L, pl), dtype=np.uint8)
+        qs = np.ascontiguousarray(qx[first:first + n])
+        dat = host.McData(n, L, pl, ua32.ctypes.data, part.ctypes.data)
+        hl.mc_bootstrap_genotypes(C.byref(opt), C.byref(dat), K, qs.ctypes.data, px.ctypes.data, C.byref(r2), part.ctypes.data)
+        assert np.array_equal(sim[first:first + n], part), first
+    # the generated data set is a working data set
+    ctx.set_model(K, lower_bound=lb)
+    ctx.set_q(0, qx)
+    ctx.set_p(0, px)
+    ll = ctx.em_step(0, 0)
+    assert np.isfinite(ll) and ctx.em_step(0, 0) > ll
+    np.testing.assert_allclose(ctx.expected_counts().sum(axis=1), float(pl) * L, rtol=1e-13)
+    ctx.close()
+
+
 def test_beyond_2_pow_32_allele_copies():
     """22 000 x 100 000 diploid = 4.4e9 allele copies: more bytes per genotype layout than a launch has work-items.
     Identities that hold at any size: the genotype comes back from the device layouts; logL(all individuals) =

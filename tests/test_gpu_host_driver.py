@@ -11,6 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 def make_fit(g, accel=0, **kw):
+    if g.name.endswith("tinybound"):
+        kw.setdefault("lower_bound", 1e-120)       # --bound on the fixture's command line
     fit = host.Fit(g.ua, g.geno, g.K, admixture=g.m["admixture"], eta_constrained=g.m["eta_constrained"],
                    do_projection=g.m["do_projection"], accel_scheme=accel, verbosity=1, **kw)
     assert fit.opt.lower_bound == g.lower_bound
@@ -58,8 +60,15 @@ def test_long_em_run_stays_on_the_reference_trajectory(name):
     fit.close()
 
 
+# mixture model (accel_em.c:444-541 over vetak): mixslow converges slowly enough for 5-7 cycles; mixlong's log likelihoods
+# come from logL_mixture's scaling branch (log_likelihood.c:209-224)
+MIX_ACCEL = ["mixslow_mix_k3_s1", "mixslow_mix_k3_s2", "mixslow_mix_k3_s3", "mixslow_mix_k3_qn1", "mixlong_mix_k3",
+             "mixlong_mix_k3_s1", "multi_mix_k3"]
+
+
 @pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "multi_admix_k4_s1", "multi_admix_k4_s2",
-                                  "multi_admix_k3_qn1", "tetra_admix_k3", "missing_admix_k3", "multi_admix_c_k3"])
+                                  "multi_admix_k3_qn1", "tetra_admix_k3", "missing_admix_k3", "multi_admix_c_k3",
+                                  "multi_admix_k4_tinybound"] + MIX_ACCEL)
 def test_accelerated_cycles_trace(name):
     """First cycles of SQUAREM / QN1 against the reference's recorded emll, step size, ll, accept, ring index."""
     g = Golden(name)
@@ -92,7 +101,7 @@ def test_accelerated_cycles_trace(name):
     fit.close()
 
 
-@pytest.mark.parametrize("name", ["multi_admix_k3_qn2", "multi_admix_k3_qn3"])
+@pytest.mark.parametrize("name", ["multi_admix_k3_qn2", "multi_admix_k3_qn3", "mixslow_mix_k3_qn2", "mixslow_mix_k3_qn3"])
 def test_quasi_newton_q2_q3_first_cycle(name):
     g = Golden(name)
     fit = make_fit(g, accel=g.m["accel_scheme"])
@@ -110,6 +119,59 @@ def test_quasi_newton_q2_q3_first_cycle(name):
     assert m.last_accepted == trace[0, 3]
     assert m.n_iter == trace[0, 4] and m.pindex == trace[0, 6]
     np.testing.assert_allclose(fit.get_p(m.pindex), g.p("cycle1"), rtol=1e-6, atol=1e-10)
+    fit.close()
+
+
+@pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "multi_admix_k4_s1", "multi_admix_k4_s2", "multi_admix_k3_qn1",
+                                  "tetra_admix_k3", "missing_admix_k3", "multi_admix_c_k3", "multi_admix_k4_tinybound",
+                                  "mixslow_mix_k3_s3", "mixslow_mix_k3_qn1"])
+def test_whole_accelerated_run_on_the_reference_path(name):
+    """The whole -s run, cycle by cycle with the calls of accelerated_em_step (accel_em.c:35-114), against the reference's
+    recorded trace (emll, step, ll, accept, n_iter per cycle) and its final iterate.  The accept test ll > emll is a
+    last-bit tie whenever the step was clamped to -1 (the extrapolated point then IS the second EM iterate); only on such
+    cycles (|ll - emll| <= 1e-9 |emll| in the reference's own record) the recorded flag is followed instead of our own
+    comparison, everywhere else our own decision must equal the reference's.  With the path pinned like this the run ends
+    at the reference's iteration with north_star's tolerances: logL 1e-8 absolute, Q/P 1e-6 relative."""
+    g = Golden(name)
+    fit = make_fit(g, accel=g.m["accel_scheme"], abs_error=g.m["abs_error"])
+    trace = g.f64("accel_trace.f64").reshape(-1, 8)
+    m = fit.mod
+    lib = fit.lib
+    for c in range(len(trace) + 1):
+        lib.mc_em_2_steps(fit.mp, fit.dat, fit.opt)
+        assert m.fatal == 0
+        if m.stopped:
+            break
+        assert c < len(trace), "the reference had stopped by now"
+        emll = lib.mc_log_likelihood(*fit._a(), m.findex)
+        assert abs(emll - trace[c, 0]) <= 1e-8, (c, emll, trace[c, 0])
+        s = lib.mc_step_size(*fit._a())
+        valid = not (np.isnan(s) or np.isinf(s))
+        assert valid == bool(trace[c, 7]), c
+        accept = False
+        if valid:
+            assert abs(s - trace[c, 1]) <= 1e-6 * abs(trace[c, 1]), (c, s, trace[c, 1])
+            ll = lib.mc_accelerated_update(*fit._a(), s)
+            assert abs(ll - trace[c, 2]) <= 1e-7 * max(1.0, abs(trace[c, 2]) * 1e-3), (c, ll, trace[c, 2])
+            tie = abs(trace[c, 2] - trace[c, 0]) <= 1e-9 * abs(trace[c, 0])
+            accept = ll > emll
+            if tie:
+                accept = bool(trace[c, 3])
+            else:
+                assert accept == bool(trace[c, 3]), (c, ll, emll, trace[c])
+        if accept:
+            m.pindex = m.tindex
+            m.accel_step = 1
+        else:
+            m.pindex = m.findex
+        assert m.n_iter == trace[c, 4] and m.pindex == trace[c, 6], c
+        assert abs(m.logL - trace[c, 5]) <= 1e-8, c
+    assert m.n_iter == g.m["accel_run_n_iter"] and m.converged == g.m["accel_run_converged"]
+    assert m.pindex == g.m["accel_run_pindex"]
+    assert abs(m.logL - g.m["accel_run_logL"]) <= 1e-8, (m.logL, g.m["accel_run_logL"])
+    np.testing.assert_allclose(fit.get_q(m.pindex), g.q("accelrun"), rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(fit.get_p(m.pindex), g.p("accelrun"), rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(fit.expected_counts(), g.sik("accelrun"), rtol=1e-6, atol=1e-9)
     fit.close()
 
 
@@ -221,7 +283,8 @@ def test_batched_em_iteration_cap_and_decrease_detection():
 
 
 @pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "multi_admix_k4_s1", "multi_admix_k4_s2",
-                                  "multi_admix_k3_qn1", "tetra_admix_k3", "missing_admix_k3", "multi_admix_c_k3"])
+                                  "multi_admix_k3_qn1", "tetra_admix_k3", "missing_admix_k3", "multi_admix_c_k3",
+                                  "multi_admix_k4_tinybound"] + MIX_ACCEL)
 def test_batched_accelerated_run_equals_cycle_by_cycle(name, monkeypatch):
     """mc_em with an acceleration scheme runs its cycles in device-side batches (mchip_accel_run: stop rule, step size and
     accept test decided by one-thread kernels, one captured graph per cycle).  Same arithmetic as the cycle-by-cycle host

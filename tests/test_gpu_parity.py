@@ -16,6 +16,10 @@ from synth import make_dataset, random_params
 pytestmark = pytest.mark.gpu
 
 ADMIX = ["c1_admix_k3", "multi_admix_k4", "tetra_admix_k3", "missing_admix_k3", "multi_admix_k1"]
+# --projection (unobserved allele columns -- the phantom slot of loci with missing data, alleles with no carrier in a cluster --
+# keep p = 0 for every k) and --bound 1e-120: the reciprocal-per-cell kernel variants (mchip_set_model)
+UNPROJECTED = ["missing_admix_k3_noproj", "multi_admix_k4_noproj", "rare_admix_k3_noproj", "tetra_admix_k3_noproj",
+               "multi_admix_k4_tinybound"]
 
 
 @pytest.fixture(scope="module")
@@ -45,7 +49,7 @@ def test_param_roundtrip(ctx, name):
     assert np.array_equal(ctx.get_q(0), g.q("q0"))
 
 
-@pytest.mark.parametrize("name", ADMIX + ["multi_admix_c_k3"])
+@pytest.mark.parametrize("name", ADMIX + ["multi_admix_c_k3"] + UNPROJECTED)
 def test_em_steps_vs_reference_golden(ctx, name):
     g = Golden(name)
     setup_case(ctx, g)
@@ -173,7 +177,9 @@ def test_invalid_inputs_are_rejected(ctx):
         ctx.set_model(0)
 
 
-MIX = ["multi_mix_k3", "missing_mix_k2"]
+# mixlong: 1 800 loci, exp(max_k v_ik) underflows, so the reference's logL_mixture takes its scaling branch
+# (log_likelihood.c:209-224) for ll_after_em
+MIX = ["multi_mix_k3", "missing_mix_k2", "mixlong_mix_k3", "mixslow_mix_k3_s3"]
 
 
 @pytest.mark.parametrize("name", MIX)
@@ -298,3 +304,35 @@ def test_accel_vector_ops_vs_numpy(ctx):
         for k in range(g.K):
             np.testing.assert_allclose(got_p[k, off:off + M], ob.michelot(want_p[k, off:off + M], lb), rtol=1e-13, atol=1e-16)
         off += M
+
+
+@pytest.mark.parametrize("name", ["rare_admix_k3_noproj", "rare_admix_k3_bs", "multi_admix_k4_noproj"])
+def test_em_on_bootstrap_replicate_lacking_alleles(ctx, name):
+    """What run_bootstrap's fits do (multiclust.c:675-708): a data set simulated from fitted parameters (on the device,
+    byte-identical to the reference's), initialised from the OBSERVED haplotypes (rnd_init.c:471), then EM steps on the
+    simulated counts.  The replicate lacks some alleles (bs_absent_columns): with --projection their columns are 0 for
+    every k, with projection they sit at the lower bound."""
+    g = Golden(name)
+    assert g.m["bs_absent_columns"] > 0
+    window, _ = ob.glibc_window(g.m["bootstrap_seed"])
+    ctx.simulate_genotypes(g.I, g.L, g.ploidy, g.ua, window, g.K, g.q("bs"), g.p("bs"))
+    sim = ctx.get_genotypes()
+    from test_bootstrap_cpu import counts_of, golden_bootstrap
+    assert np.array_equal(counts_of(sim, g.ua), golden_bootstrap(g))
+    ctx.set_init_genotypes(g.geno)
+    ctx.set_model(g.K, do_projection=g.m["do_projection"], lower_bound=g.lower_bound)
+    w0, _ = ob.glibc_window(g.m["seed"])
+    ctx.mstep_from_rand_partition(w0, 0)
+    close(ctx.get_q(0), g.q("bsinit"), 1e-15, 1e-18)
+    close(ctx.get_p(0), g.p("bsinit"), 1e-15, 1e-18)
+    ll_ref = g.f64("bs_em_ll.f64")
+    for s in range(g.m["bs_em_steps"]):
+        ll = ctx.em_step(0, 0)
+        assert np.isfinite(ll) and abs(ll - ll_ref[s]) <= 1e-8, (s, ll, ll_ref[s])
+    close(ctx.get_q(0), g.q("bsstep"), 1e-9, 1e-13)
+    close(ctx.get_p(0), g.p("bsstep"), 1e-9, 1e-13)
+    close(ctx.expected_counts(), g.sik("bsstep"), 1e-9, 1e-12)
+    assert abs(ctx.loglik(0) - g.m["bs_ll_after_em"]) <= 1e-8
+    if not g.m["do_projection"]:
+        absent = counts_of(sim, g.ua).sum(axis=0) == 0
+        assert np.all(ctx.get_p(0)[:, absent] == 0.0)
