@@ -171,6 +171,25 @@ int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to
 int mchip_mstep_from_rand_partition(mchip_context *ctx, const uint32_t *window, int to);
 
 /*
+ * One Rand-EM candidate: random_allele_center's partition + initialize_parameters_admixture (rnd_init.c:496-705) into slot
+ * `to`.  The host walks the loci in order and draws each locus's center alleles from the rand() stream exactly as the
+ * reference does (K draws plus uniqueness retries when the locus has at least K alleles, none otherwise), which also tells it
+ * how many copies of the locus match no center and therefore where each locus's rand() % K draws lie in the stream:
+ *   centers[l*K + k]  allele index of cluster k's center at locus l, 0xFF = none (the reference's -1);
+ *   draw_offset[l]    position, counted from `window`, of the first draw that a non-matching copy of locus l consumes
+ *                     (copies take them in i, a order; missing copies match no center);
+ *   window, n_draws   the 31 words behind the candidate's first draw (as mchip_mstep_from_rand_partition) and the length
+ *                     of the candidate's span of the stream.
+ * The device assigns every copy (identity with a center, else its draw), counts -- eta_ik = (1 + copies of i in k) /
+ * (ploidy L + K), missing copies included; p_klm = (1 + copies of allele m in k) / sum_m -- and normalises; nothing is
+ * projected.  Reads the observed haplotypes when mchip_set_init_genotypes is in force (the reference reads dat->IL).
+ */
+int mchip_init_from_allele_centers(mchip_context *ctx, const uint8_t *centers, const uint64_t *draw_offset, const uint32_t *window,
+				   uint64_t n_draws, int to);
+/* parameters of slot `from` copied to slot `to`: Rand-EM keeps its best candidate (rnd_init.c:431-436 keeps the partition) */
+int mchip_copy_slot(mchip_context *ctx, int to, int from);
+
+/*
  * What the writers read from diklm / vik (write_file.c:359-381,446-459,531-542,593-598):
  * admixture: sik[i][k] = sum_{l,m} d_iklm of the last E step executed; mixture: vik[i][k].
  */

@@ -291,6 +291,40 @@ __global__ __launch_bounds__(256) void k_simulate_admixture(rng_window base, con
 	}
 }
 
+/* random_allele_center's assignment (rnd_init.c:552-580) given the centers the host drew: copy (i, a) of locus l goes to the
+ * first cluster k whose center allele it carries; a copy that matches no center (a missing copy never does) takes the next
+ * value of rand() % K, in i, a order within the locus.  lane = locus: the locus's non-matching copies are numbered by the
+ * lane's own running count, their draws start draw_offset[l] into the byte stream `draws` (rand() % K of the candidate's
+ * whole stream span, from k_draw_partition).  Writes the partition in stream-independent raw order [I][L][pl]. */
+__global__ __launch_bounds__(256) void k_assign_by_centers(const uint8_t *__restrict__ gtA, int I, int L, int pl, int K,
+		const uint8_t *__restrict__ centers, const unsigned long long *__restrict__ draw_offset,
+		const uint8_t *__restrict__ draws, uint8_t *raw)
+{
+	const int l = blockIdx.x * 256 + threadIdx.x;
+	if (l >= L) return;
+	uint8_t cen[MCHIP_MAX_K];
+	for (int k = 0; k < K; k++) cen[k] = centers[(size_t)l * K + k];
+	unsigned long long next = draw_offset[l];
+	for (int ib = 0; ib < (I + 7) / 8; ib++) {
+		const uint8_t *src = gtA + ((size_t)ib * L + l) * 8 * (size_t)pl;
+		for (int j = 0; j < 8; j++) {
+			const int i = ib * 8 + j;
+			if (i >= I) break;
+			for (int b = 0; b < pl; b++) {
+				const uint8_t g = src[j * pl + b];
+				int kk = -1;
+				if (g != MCHIP_MISSING)
+					for (int k = 0; k < K; k++) {
+						if (cen[k] == 0xFF) break;	/* center[k] == -1 ends the list (rnd_init.c:562-563) */
+						if (cen[k] == g) { kk = k; break; }
+					}
+				if (kk < 0) kk = draws[next++];
+				raw[((size_t)i * L + l) * pl + b] = (uint8_t)kk;
+			}
+		}
+	}
+}
+
 /* gtA -> raw [I][L][pl] (mchip_get_genotypes) */
 __global__ void k_unlayout(const uint8_t *__restrict__ gtA, int I, int L, int pl, uint8_t *raw)
 {
@@ -503,12 +537,12 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_sums(const double *__res
 	}
 	if (threadIdx.x == 0) out[k] = red[0];
 }
-__global__ void k_normalize_row(const double *__restrict__ sums, int K, double *eta, const int *stop = nullptr)
+__global__ void k_normalize_row(const double *__restrict__ sums, int K, double *eta, const int *stop = nullptr, double add = 0.0)
 {
 	if (threadIdx.x || blockIdx.x || (stop && *stop)) return;
 	double temp = 0.0;
-	for (int k = 0; k < K; k++) temp += sums[k];
-	for (int k = 0; k < K; k++) eta[k] = sums[k] / temp;
+	for (int k = 0; k < K; k++) temp += sums[k] + add;
+	for (int k = 0; k < K; k++) eta[k] = (sums[k] + add) / temp;
 }
 
 /* mixture model: log P table; the E step skips p == 0 cells (em_alg.c:797-804), logL_mixture does not
@@ -598,10 +632,13 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_dots(const double *__restrict__
 	}
 }
 
-/* accel_em.c:444-541 element updates (projection follows in k_project_*) */
+/* accel_em.c:444-541 element updates (projection follows in k_project_*).  Evaluated exactly as the reference's expression
+ * (left to right, every product and sum rounded: no fused multiply-add): where the extrapolation cancels to about zero, the
+ * last bits decide whether the projection clamps the entry to the lower bound */
 __global__ void k_accel_update(const double *__restrict__ base, const double *__restrict__ u, const double *__restrict__ v,
 			       double *out, size_t n, double s, int qn_form, const double *s_dev = nullptr, const int *stop = nullptr)
 {
+#pragma clang fp contract(off)
 	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (idx >= n || (stop && *stop)) return;
 	if (s_dev) s = *s_dev;		/* batched accelerated runs: the step size was computed on the device */
@@ -610,6 +647,7 @@ __global__ void k_accel_update(const double *__restrict__ base, const double *__
 }
 __global__ void k_axpy2(const double *__restrict__ v, double *out, size_t n, double ca, double cb)
 {
+#pragma clang fp contract(off)
 	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (idx < n) out[idx] += v[idx] * ca * cb;	/* accel_em.c:387-393: v * Ainv * cutu */
 }
@@ -1168,11 +1206,11 @@ static int fetch_scalars(mchip_context *ctx, int first, int count, double *out)
 }
 
 /* shared eta: eta[to] = normalise(sum_i S_ik), project (em_alg.c:604-648) */
-static int finalize_shared_eta(mchip_context *ctx, int to, const int *stop = nullptr)
+static int finalize_shared_eta(mchip_context *ctx, int to, const int *stop = nullptr, double add = 0.0, int project = 1)
 {
 	hipLaunchKernelGGL(k_column_sums, dim3(ctx->K), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_sik, ctx->I, ctx->K, ctx->d_scalars + 8, stop);
-	hipLaunchKernelGGL(k_normalize_row, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars + 8, ctx->K, ctx->d_q[to], stop);
-	if (ctx->do_projection) ctx->kt->project_q(1, ctx->K, ctx->d_q[to], ctx->eta_lb, stop, ctx->stream);
+	hipLaunchKernelGGL(k_normalize_row, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars + 8, ctx->K, ctx->d_q[to], stop, add);
+	if (ctx->do_projection && project) ctx->kt->project_q(1, ctx->K, ctx->d_q[to], ctx->eta_lb, stop, ctx->stream);
 	HIPCHK(hipGetLastError());
 	return MCHIP_OK;
 }
@@ -1240,7 +1278,7 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 		hipLaunchKernelGGL(k_sum_slabs, dim3(nblk(n, 32)), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_Spart, ctx->n_lchunks, n, ctx->d_ssum, stop);
 	}
 	ctx->kt->finalize_q(ctx->I, ctx->K, 1, ctx->d_ssum, ctx->d_q[from], ctx->qstride,
-			    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream);
+			    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream, 0.0);
 	if (do_mstep) {
 		if (!indiv) {
 			int rc = finalize_shared_eta(ctx, to, stop);
@@ -1361,8 +1399,10 @@ int mchip_loglik_prefetch(mchip_context *ctx, int slot, double *loglik)
 	return MCHIP_OK;
 }
 
-/* relayout of a partition held on the device in stream order, then the hard-partition M step into slot `to` */
-static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to)
+/* relayout of a partition held on the device in stream order, then the hard-partition M step into slot `to`
+ * (counts = 0: random_initialize_admixture, rnd_init.c:349-357), or initialize_parameters_admixture (rnd_init.c:603-705)
+ * from that partition (counts = 1: one count per copy on top of 1, normalised, never projected) */
+static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to, int counts = 0)
 {
 	int rc;
 	if (!ctx->d_asA) HIPCHK(hipMalloc((void **)&ctx->d_asA, ctx->geno_bytes_A));
@@ -1383,15 +1423,18 @@ static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to)
 		a.gtA = ctx->d_initA;
 		a.gtS = ctx->d_initS;
 	}
+	a.part_counts = counts;
 	ctx->kt->part_p(a, ctx->stream);
 	ctx->kt->part_q(a, ctx->stream);
 	const int indiv = ctx->qstride != 0;
+	const int project = counts ? 0 : ctx->do_projection;
+	const double add = counts ? 1.0 : 0.0;
 	ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[to], ctx->qstride,
-			    ctx->d_q[to], ctx->d_sik, indiv, 0, ctx->do_projection, ctx->eta_lb, nullptr, ctx->stream);
-	if (!indiv && (rc = finalize_shared_eta(ctx, to))) return rc;
+			    ctx->d_q[to], ctx->d_sik, indiv, 0, project, ctx->eta_lb, nullptr, ctx->stream, add);
+	if (!indiv && (rc = finalize_shared_eta(ctx, to, nullptr, add, !counts))) return rc;
 	hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
 			   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[to], ctx->d_p[to],
-			   0, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags);
+			   0, add, project, ctx->p_lb, ctx->d_flags);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	return MCHIP_OK;
@@ -1501,6 +1544,63 @@ int mchip_mstep_from_rand_partition(mchip_context *ctx, const uint32_t *window, 
 		HIPCHK(hipGetLastError());
 	}
 	return partition_mstep(ctx, ctx->d_draw, to);
+}
+
+int mchip_init_from_allele_centers(mchip_context *ctx, const uint8_t *centers, const uint64_t *draw_offset, const uint32_t *window,
+				   uint64_t n_draws, int to)
+{
+	int rc = check_partition_call(ctx, centers, to);
+	if (rc) return rc;
+	if (!draw_offset || !window) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
+	/* rand() % K for the candidate's whole span of the stream (center draws included: the host knows which draws are whose) */
+	scoped_dev<uint8_t> d_span, d_cen, d_raw;
+	scoped_dev<unsigned long long> d_off;
+	rng_window base;
+	size_t n_chunks = 0, n_blocks = 0;
+	if (n_draws) {
+		if ((rc = rng_stream_setup(ctx, window, (size_t)n_draws, &base, &n_chunks, &n_blocks))) return rc;
+		HIPCHK(d_span.alloc(n_chunks * RNG_CHUNK));
+		if (ctx->K == 1) {
+			HIPCHK(hipMemsetAsync(d_span, 0, n_chunks * RNG_CHUNK, ctx->stream));
+		} else {
+			uint32_t l = 0;
+			while ((1u << l) < (uint32_t)ctx->K) l++;
+			const uint64_t pw = (uint64_t)1 << (31 + l);
+			const uint32_t magic = (uint32_t)((pw + (uint64_t)ctx->K - 1) / (uint64_t)ctx->K);
+			hipLaunchKernelGGL(k_draw_partition, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, base, ctx->d_jump_hi,
+					   ctx->d_jump_lo, n_chunks, (uint32_t)ctx->K, magic, l - 1, (uint32_t *)d_span.p);
+		}
+	} else {
+		HIPCHK(d_span.alloc(16));	/* no copy draws: never read */
+	}
+	/* every offset must leave room for the locus's copies inside the span: a locus reads at most I*ploidy draws */
+	for (int l = 0; l < ctx->L; l++)
+		if (draw_offset[l] > n_draws) return fail(ctx, MCHIP_ERR_INVALID, "draw offset beyond the stream span%s", nullptr);
+	HIPCHK(d_cen.alloc((size_t)ctx->L * ctx->K));
+	HIPCHK(d_off.alloc((size_t)ctx->L));
+	HIPCHK(d_raw.alloc(n));
+	HIPCHK(hipMemcpyAsync(d_cen, centers, (size_t)ctx->L * ctx->K, hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipMemcpyAsync(d_off, draw_offset, sizeof(uint64_t) * (size_t)ctx->L, hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(k_assign_by_centers, dim3(nblk((size_t)ctx->L)), dim3(256), 0, ctx->stream,
+			   ctx->d_initA ? ctx->d_initA : ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, ctx->K, d_cen.p, d_off.p, d_span.p, d_raw.p);
+	HIPCHK(hipGetLastError());
+	rc = partition_mstep(ctx, d_raw, to, 1);
+	(void)hipStreamSynchronize(ctx->stream);	/* the temporaries go out of scope */
+	return rc;
+}
+
+int mchip_copy_slot(mchip_context *ctx, int to, int from)
+{
+	int rc = check_slot(ctx, to);
+	if (rc || (rc = check_slot(ctx, from))) return rc;
+	if (to == from) return MCHIP_OK;
+	ctx->s_cache_slot = -1;
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipMemcpyAsync(ctx->d_p[to], ctx->d_p[from], (size_t)ctx->K * ctx->T * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+	HIPCHK(hipMemcpyAsync(ctx->d_q[to], ctx->d_q[from], (size_t)ctx->nq * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+	return MCHIP_OK;
 }
 
 int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, const uint32_t *window,

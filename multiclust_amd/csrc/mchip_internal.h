@@ -60,6 +60,8 @@ struct mchip_pass_args {
 	const int *skip_ind;
 	/* hard-partition first M step */
 	const uint8_t *asA, *asS;	/* assignment bytes in the gtA / gtS layouts */
+	int part_counts;		/* 0: d_iklm = 1 per (allele, cluster) pair, missing copies skipped (random_allele_partition);
+					 * 1: one count per copy, missing copies count for the individual (initialize_parameters_admixture) */
 };
 
 /* per-K kernel table (one translation unit per K keeps each hipcc job small and `make -j` parallel) */
@@ -71,7 +73,8 @@ struct mchip_ktable {
 	void (*part_q)(const mchip_pass_args &a, hipStream_t s);	/* hard partition, individual pass */
 	/* finalize: Q[to] from Spart (normalise + project), stores expected counts */
 	void (*finalize_q)(int I, int K, int n_lchunks, const double *Spart, const double *Qfrom, int qstride_from,
-			   double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, const int *stop, hipStream_t s);
+			   double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, const int *stop, hipStream_t s,
+			   double add);
 	void (*project_q)(int nrows, int K, double *Q, double lb, const int *stop, hipStream_t s);
 	/* mixture model */
 	void (*mix_gather)(const mchip_pass_args &a, hipStream_t s);	/* a.P = log P table; Spart = per-chunk sums */

@@ -774,6 +774,15 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_partition_columns(mchip_pass_ar
 		s.load(a.asA, (size_t)ib * a.L + l, pl);
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
+			if (a.part_counts) {	/* initialize_parameters_admixture (rnd_init.c:661-684): every copy counts */
+				for (int b = 0; b < pl; b++)
+					if (g.copy(j, b, pl) == m) {
+						const unsigned kb = s.copy(j, b, pl);
+#pragma unroll
+						for (int k = 0; k < K; k++) acc[k] += (kb == (unsigned)k) ? 1.0 : 0.0;
+					}
+				continue;
+			}
 			unsigned flags = 0;
 			for (int b = 0; b < pl; b++)
 				if (g.copy(j, b, pl) == m) flags |= 1u << (s.copy(j, b, pl) & 31u);
@@ -807,11 +816,13 @@ __global__ __launch_bounds__(QBLOCK) void k_partition_individuals(mchip_pass_arg
 			if (lb * 8 + j >= l1) break;
 			for (int b = 0; b < pl; b++) {
 				const unsigned mb = g.copy(j, b, pl), kb = s.copy(j, b, pl);
-				if (mb == MCHIP_MISSING) continue;
-				bool dup = false;
-				for (int b2 = 0; b2 < b; b2++)
-					dup |= (g.copy(j, b2, pl) == mb) && (s.copy(j, b2, pl) == kb);
-				if (dup) continue;
+				if (!a.part_counts) {
+					if (mb == MCHIP_MISSING) continue;
+					bool dup = false;
+					for (int b2 = 0; b2 < b; b2++)
+						dup |= (g.copy(j, b2, pl) == mb) && (s.copy(j, b2, pl) == kb);
+					if (dup) continue;
+				}	/* else initialize_parameters_admixture (rnd_init.c:617-648): every copy of the individual, missing ones too */
 #pragma unroll
 				for (int k = 0; k < K; k++) acc[k] += (kb == (unsigned)k) ? 1.0 : 0.0;
 			}
@@ -852,7 +863,7 @@ __device__ __forceinline__ void michelot_k(double (&x)[K], double mn)
  * expected counts S_ik the writers need (write_file.c:359-381). */
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_q(int I, int n_lchunks, const double *__restrict__ Spart,
 		const double *__restrict__ Qfrom, int qstride_from, double *Qto, double *sik,
-		int do_mstep, int weighted, int do_projection, double lb, const int *stop)
+		int do_mstep, int weighted, int do_projection, double lb, const int *stop, double add)
 {
 	const int i = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
 	if (i >= I || (stop && *stop)) return;
@@ -873,7 +884,10 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_q(int I, int n_lchunks
 	if (!do_mstep) return;
 	double temp = 0.0;
 #pragma unroll
-	for (int k = 0; k < K; k++) temp += s[k];
+	for (int k = 0; k < K; k++) {
+		s[k] += add;		/* 0, or the 1 every count of initialize_parameters_admixture starts from (rnd_init.c:624) */
+		temp += s[k];
+	}
 #pragma unroll
 	for (int k = 0; k < K; k++) s[k] /= temp;
 	if (do_projection) michelot_k(s, lb);
@@ -979,10 +993,11 @@ void launch_part_q(const mchip_pass_args &a, hipStream_t s)
 	else hipLaunchKernelGGL((k_partition_individuals<0>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
 }
 void launch_finalize_q(int I, int, int n_lchunks, const double *Spart, const double *Qfrom, int qstride_from,
-		       double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, const int *stop, hipStream_t s)
+		       double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, const int *stop, hipStream_t s,
+		       double add)
 {
 	hipLaunchKernelGGL(k_finalize_q, dim3((I + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s,
-			   I, n_lchunks, Spart, Qfrom, qstride_from, Qto, sik, do_mstep, weighted, do_projection, lb, stop);
+			   I, n_lchunks, Spart, Qfrom, qstride_from, Qto, sik, do_mstep, weighted, do_projection, lb, stop, add);
 }
 void launch_project_q(int nrows, int, double *Q, double lb, const int *stop, hipStream_t s)
 {

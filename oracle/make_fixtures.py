@@ -67,6 +67,10 @@ BOOTSTRAP_CASES = ("multi_admix_k4", "tetra_admix_k3", "missing_admix_k3", "mult
 # section 6b as well: EM steps on the simulated data set (projection off: alleles the replicate lacks keep p = 0)
 BOOTSTRAP_EM_CASES = ("multi_admix_k4_noproj", "rare_admix_k3_noproj", "rare_admix_k3_bs")
 # section 7: Rand-EM initialisation with this many candidates
+# section 3b also records the iterate every accelerated cycle starts from (stride 1 = every cycle; n: cycles c, c+1 of every n)
+CYCLE_STATE_CASES = {"c1_admix_k3": 6, "multi_admix_k4": 1, "multi_admix_k4_s1": 1, "multi_admix_k4_s2": 1,
+                     "multi_admix_k3_qn1": 1, "tetra_admix_k3": 1, "missing_admix_k3": 1, "multi_admix_c_k3": 1,
+                     "multi_admix_k4_tinybound": 2, "mixslow_mix_k3_s3": 1, "mixslow_mix_k3_qn1": 1}
 RANDEM_CASES = {"multi_admix_k3_randem": 6, "wide_admix_k2_randem": 5, "tetra_admix_k3_randem": 4,
                 "missing_admix_k2_randem": 5, "multi_admix_c_k3_randem": 4, "multi_mix_k3_randem": 5}
 
@@ -82,6 +86,8 @@ def run(name, stru, n_em, snaps, n_cycles, args, keep_ilm=True):
         env["REF_HARNESS_BOOTSTRAP"] = "1"
     if name in BOOTSTRAP_EM_CASES:
         env["REF_HARNESS_BOOTSTRAP"] = "2"
+    if name in CYCLE_STATE_CASES:
+        env["REF_HARNESS_CYCLE_STATES"] = str(CYCLE_STATE_CASES[name])
     if name in RANDEM_CASES:
         env["REF_HARNESS_RANDEM"] = str(RANDEM_CASES[name])
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, cwd=out, env=env)

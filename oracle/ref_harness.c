@@ -317,8 +317,25 @@ int main(int argc, const char **argv)
 		}
 		f = xopen("accel_trace.f64");
 		FILE *fu = NULL;
+		/* REF_HARNESS_CYCLE_STATES=<stride>: the iterate every cycle starts from (slot pindex), for cycles c with c % stride
+		 * <= 1 (stride 1: every cycle), so that each cycle of the whole run can be checked from the reference's own state */
+		const int st_stride = getenv("REF_HARNESS_CYCLE_STATES") ? atoi(getenv("REF_HARNESS_CYCLE_STATES")) : 0;
+		FILE *fs = st_stride > 0 ? xopen("accel_states.f64") : NULL;
+		int n_states = 0;
 		if (!mod->converged) do {
 			double rec[8] = {0};
+			if (fs && (st_stride == 1 || cyc % st_stride <= 1)) {
+				double c = cyc;
+				fwrite(&c, sizeof c, 1, fs);
+				if (opt->admixture && !opt->eta_constrained)
+					for (int i = 0; i < dat->I; i++) fwrite(mod->vetaik[mod->pindex][i], sizeof(double), mod->K, fs);
+				else
+					fwrite(mod->vetak[mod->pindex], sizeof(double), mod->K, fs);
+				for (int k = 0; k < mod->K; k++)
+					for (int l = 0; l < dat->L; l++)
+						fwrite(mod->vpklm[mod->pindex][k][l], sizeof(double), dat->uniquealleles[l], fs);
+				n_states++;
+			}
 			em_2_steps(mod, dat, opt);
 			if (mod->stopped) { stop_flag = 1; break; }
 			double emll = log_likelihood(opt, dat, mod, mod->findex);
@@ -368,6 +385,11 @@ int main(int argc, const char **argv)
 			}
 		} while (!stop_flag);
 		fclose(f);
+		if (fs) {
+			fclose(fs);
+			man_int("accel_states", n_states);
+			man_int("accel_states_stride", st_stride);
+		}
 		man_int("accel_trace_cycles", cyc);
 		man_int("accel_snapshot_cycle", n_cycles);
 		if (mod->n_iter != ref_n_iter || mod->logL != ref_logL || mod->converged != ref_conv
