@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_assign_by_centers(const uint8_t *__rest
 						if (cen[k] == 0xFF) break;	/* center[k] == -1 ends the list (rnd_init.c:562-563) */
 						if (cen[k] == g) { kk = k; break; }
 					}
-				if (kk < 0) kk = draws[next++];
+				if (kk < 0) kk = (K == 1) ? 0 : draws[next++];	/* K = 1: every copy to cluster 0, nothing drawn */
 				raw[((size_t)i * L + l) * pl + b] = (uint8_t)kk;
 			}
 		}

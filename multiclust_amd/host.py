@@ -15,7 +15,8 @@ class McOptions(C.Structure):
                 ("accel_scheme", C.c_int), ("q", C.c_int), ("n_init_iter", C.c_int), ("max_iter", C.c_int),
                 ("n_seconds", C.c_uint), ("adjust_step", C.c_int), ("verbosity", C.c_int),
                 ("abs_error", C.c_double), ("rel_error", C.c_double), ("lower_bound", C.c_double),
-                ("eta_lower_bound", C.c_double), ("p_lower_bound", C.c_double), ("seed", C.c_uint)]
+                ("eta_lower_bound", C.c_double), ("p_lower_bound", C.c_double), ("seed", C.c_uint),
+                ("initialization_procedure", C.c_int), ("n_rand_em_init", C.c_int)]
 
 
 class McData(C.Structure):
@@ -30,7 +31,7 @@ class McModel(C.Structure):
                 ("fatal", C.c_int), ("start", C.c_long), ("seconds_run", C.c_double),
                 ("A", C.c_double * 9), ("Ainv", C.c_double * 9), ("cutu", C.c_double * 3),
                 ("last_emll", C.c_double), ("last_step", C.c_double), ("last_ll", C.c_double),
-                ("last_accepted", C.c_int), ("dev", C.c_void_p), ("owns_dev", C.c_int)]
+                ("last_accepted", C.c_int), ("dev", C.c_void_p), ("owns_dev", C.c_int), ("init_cache", C.c_void_p)]
 
 
 class McRng(C.Structure):
@@ -81,6 +82,7 @@ def load():
     lib.mc_model_get_expected_counts.argtypes = [MP, C.c_void_p]
     lib.mc_initialize_model.argtypes = [OP, DP, MP, C.POINTER(McRng)]
     lib.mc_reset_model_state.argtypes = [MP]
+    lib.mc_skip_initializations.argtypes = [OP, DP, MP, C.POINTER(McRng), C.c_int]
     lib.mc_em.argtypes = [OP, DP, MP]
     lib.mc_em.restype = None
     lib.mc_em_step.argtypes = [OP, DP, MP]

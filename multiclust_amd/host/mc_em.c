@@ -53,6 +53,8 @@ void mc_make_options(mc_options *opt)
 	opt->do_projection = 1;
 	opt->q = 1;
 	opt->verbosity = MC_MINIMAL;
+	opt->initialization_procedure = MC_INIT_NOTHING;	/* multiclust.c:935 */
+	opt->n_rand_em_init = 50;				/* multiclust.c:936 */
 }
 
 int mc_synchronize(mc_options *opt, const mc_data *dat)
@@ -211,6 +213,7 @@ void mc_simulation_begin(mc_simulation *sim, const mc_options *opt, const mc_dat
 void mc_model_free(mc_model *mod)
 {
 	if (!mod) return;
+	mc_init_cache_free(mod);
 	if (mod->owns_dev && mod->dev) mchip_destroy(mod->dev);
 	free(mod);
 }
@@ -221,86 +224,6 @@ int mc_model_get_p(mc_model *mod, int slot, double *p) { return mchip_get_p(mod-
 int mc_model_set_q(mc_model *mod, int slot, const double *q) { return mchip_set_q(mod->dev, slot, q); }
 int mc_model_get_q(mc_model *mod, int slot, double *q) { return mchip_get_q(mod->dev, slot, q); }
 int mc_model_get_expected_counts(mc_model *mod, double *sik) { return mchip_get_expected_counts(mod->dev, sik); }
-
-/* random_initialize_mixture (rnd_init.c:103-110) with the default RANDOM_CENTERS method: random_individual_center
- * (192-259) then initialize_parameters_mixture (268-339), on the host from the genotype (allele counts are rebuilt
- * per locus).  Kept quirk: the reference re-adds every individual's counts inside its loop over k
- * (rnd_init.c:296-318), so cluster k ends with 1 + (K-k) * (its allele counts) before normalisation. */
-static int initialize_mixture(const mc_data *dat, mc_model *mod, mc_rng *rng)
-{
-	const int I = dat->I, L = dat->L, pl = dat->ploidy, K = mod->K;
-	int T = 0, rc;
-	int *toff = malloc(sizeof(int) * ((size_t)L + 1));
-	int *I_K = calloc((size_t)I, sizeof(int));
-	int center[K];
-	if (!toff || !I_K) { free(toff); free(I_K); return MCHIP_ERR_ALLOC; }
-	toff[0] = 0;
-	for (int l = 0; l < L; l++) toff[l + 1] = toff[l] + dat->uniquealleles[l];
-	T = toff[L];
-	if (K > 1) {
-		for (int k = 0; k < K; k++) {
-			int flag;
-			center[k] = mc_rand(rng) % I;
-			do {
-				flag = 0;
-				for (int j = 0; j < k; j++)
-					if (center[k] == center[j]) {
-						center[k] = mc_rand(rng) % I;
-						flag = 1;
-						break;
-					}
-			} while (flag == 1);
-		}
-		int cnt[256];
-		for (int i = 0; i < I; i++) {
-			I_K[i] = 0;
-			if (i == center[0]) continue;
-			double min_diff = INFINITY;
-			for (int k = 0; k < K; k++) {
-				if (i == center[k]) { I_K[i] = k; break; }
-				double diff = 0;
-				for (int l = 0; l < L; l++) {
-					const int M = dat->uniquealleles[l];
-					const uint8_t *gi = dat->geno + ((size_t)i * L + l) * pl;
-					const uint8_t *gc = dat->geno + ((size_t)center[k] * L + l) * pl;
-					for (int m = 0; m < M; m++) cnt[m] = 0;
-					for (int a = 0; a < pl; a++) {
-						if (gi[a] != MCHIP_MISSING) cnt[gi[a]]++;
-						if (gc[a] != MCHIP_MISSING) cnt[gc[a]]--;
-					}
-					for (int m = 0; m < M; m++) diff += abs(cnt[m]);
-				}
-				if (diff < min_diff) { I_K[i] = k; min_diff = diff; }
-			}
-		}
-	}
-	double *eta = malloc(sizeof(double) * (size_t)K), *p = malloc(sizeof(double) * (size_t)K * T);
-	if (!eta || !p) { free(eta); free(p); free(toff); free(I_K); return MCHIP_ERR_ALLOC; }
-	for (int k = 0; k < K; k++) eta[k] = 1;
-	for (int i = 0; i < I; i++) eta[I_K[i]]++;
-	for (int k = 0; k < K; k++) eta[k] /= I + K;
-	for (size_t x = 0; x < (size_t)K * T; x++) p[x] = 0.0;
-	for (int i = 0; i < I; i++)
-		for (int l = 0; l < L; l++)
-			for (int a = 0; a < pl; a++) {
-				const uint8_t m = dat->geno[((size_t)i * L + l) * pl + a];
-				if (m != MCHIP_MISSING) p[(size_t)I_K[i] * T + toff[l] + m] += 1.0;
-			}
-	for (int k = 0; k < K; k++)
-		for (int l = 0; l < L; l++) {
-			double temp = 0.0;
-			for (int m = 0; m < dat->uniquealleles[l]; m++) {
-				double *e = &p[(size_t)k * T + toff[l] + m];
-				*e = 1.0 + (K - k) * *e;
-				temp += *e;
-			}
-			for (int m = 0; m < dat->uniquealleles[l]; m++) p[(size_t)k * T + toff[l] + m] /= temp;
-		}
-	rc = mchip_set_q(mod->dev, mod->tindex, eta);
-	if (!rc) rc = mchip_set_p(mod->dev, mod->tindex, p);
-	free(eta); free(p); free(toff); free(I_K);
-	return rc;
-}
 
 /* assign[j] = rand() % K for j = 0..n-1 in stream order (rnd_init.c:467).  Large draws are split over host threads:
  * thread t starts from the stream jumped ahead to its first draw (mc_rng_jump), so the result is the serial one. */
@@ -356,8 +279,10 @@ int mc_initialize_model(const mc_options *opt, const mc_data *dat, mc_model *mod
 	mod->logL = -INFINITY;
 	mod->converged = 0;
 	if (opt->accel_scheme) mod->pindex = mod->tindex = mod->findex = 0;
+	if (opt->initialization_procedure == MC_RAND_EM)	/* rnd_init.c:80,85: opt-in, the reference's own -m never selects it */
+		return dev_fail(mod, mc_randem_initialize(opt, dat, mod, rng), "mc_initialize_model");
 	if (!opt->admixture)
-		return dev_fail(mod, initialize_mixture(dat, mod, rng), "mc_initialize_model");
+		return dev_fail(mod, mc_initialize_mixture(dat, mod, rng), "mc_initialize_model");
 	if (!getenv("MC_HOST_INIT")) {
 		/* the partition is drawn on the device from this point of the stream; the host copy of the stream moves on
 		 * by the same number of draws */

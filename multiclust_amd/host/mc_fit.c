@@ -106,7 +106,7 @@ int mc_fit_unit(const mc_options *opt, const mc_data *dat, mc_model *mod, unsign
 	int rc;
 	const int delta_keep = mod->delta_index;	/* not reset between initialisations (multiclust.c:518-524) */
 	mc_srand(&rng, seed);
-	mc_rng_jump(&rng, (uint64_t)unit * mc_draws_per_init(opt, dat, mod->K));
+	if ((rc = mc_skip_initializations(opt, dat, mod, &rng, unit))) return rc;
 	mc_reset_model_state(mod);
 	mod->delta_index = delta_keep;
 	if ((rc = mc_initialize_model(opt, dat, mod, &rng))) return rc;
@@ -138,6 +138,7 @@ int mc_fit_replicate(const mc_options *opt, const mc_data *dat, int device, cons
 	mc_simulation gen;
 	int rc = 0;
 	if (!opt->admixture) return MCHIP_ERR_UNSUPPORTED;	/* the mixture model's replicate is drawn on the host */
+	if (opt->initialization_procedure == MC_RAND_EM) return MCHIP_ERR_UNSUPPORTED;	/* no closed form for a replicate's stream position */
 	memset(out, 0, sizeof *out);
 	out->replicate = b;
 	mc_rng_jump(&rng, (uint64_t)b * per_replicate);

@@ -25,6 +25,8 @@ extern "C" {
 enum { MC_NONE = 0, MC_SQS1, MC_SQS2, MC_SQS3, MC_QN };
 /* verbosity (reference message.h:45-53) */
 enum { MC_ABSOLUTE_SILENCE = 0, MC_SILENT, MC_QUIET, MC_MINIMAL, MC_RESTRAINED, MC_TALKATIVE, MC_VERBOSE, MC_DEBUG };
+/* initialisation procedures (reference multiclust.h:107-111) */
+enum { MC_INIT_NOTHING = 0, MC_RAND_EM };
 /* fatal conditions the reference answers with exit(0) */
 enum { MC_FATAL_NONE = 0, MC_FATAL_NAN = 1, MC_FATAL_DECREASE = 2, MC_FATAL_DEVICE = 3 };
 
@@ -45,6 +47,8 @@ typedef struct mc_options {	/* subset of reference struct _options used by the E
 	double eta_lower_bound;
 	double p_lower_bound;
 	unsigned int seed;
+	int initialization_procedure;	/* MC_INIT_NOTHING (random initialisation) or MC_RAND_EM (multiclust.h:107-111) */
+	int n_rand_em_init;		/* candidates per Rand-EM initialisation (-m, multiclust.c:936,1547) */
 } mc_options;
 
 typedef struct mc_data {	/* flat form of reference struct _data's genotype fields (multiclust.h:223-237) */
@@ -69,6 +73,7 @@ typedef struct mc_model {	/* EM-layer state of reference struct _model (multiclu
 	int last_accepted;
 	mchip_context *dev;
 	int owns_dev;
+	void *init_cache;		/* per-locus allele counts of the observed haplotypes (Rand-EM), built on first use */
 } mc_model;
 
 /* glibc-compatible rand() stream (TYPE_3 additive feedback): "same seed" means the same draws as the
@@ -113,6 +118,18 @@ int mc_model_get_expected_counts(mc_model *mod, double *sik);
 /* initialize_model (rnd_init.c:54-89) for the admixture model, random allele partition (349-357,456-482) */
 int mc_initialize_model(const mc_options *opt, const mc_data *dat, mc_model *mod, mc_rng *rng);
 void mc_reset_model_state(mc_model *mod);	/* multiclust.c:518-524 + rnd_init.c:58-71 */
+/* random_initialize_mixture (rnd_init.c:103-110): random_individual_center + initialize_parameters_mixture, on the host */
+int mc_initialize_mixture(const mc_data *dat, mc_model *mod, mc_rng *rng);
+/* Rand-EM (rnd_init.c:123-160 mixture, 412-444 admixture): n_rand_em_init candidates -- random centers, parameters from the
+ * partition, one EM iteration plus an E step (em_e_step) -- and the parameters of the candidate with the best log likelihood.
+ * Admixture candidates are partitioned and counted on the device (mchip_init_from_allele_centers); the host only walks the
+ * loci to draw the centers.  Consumes `rng` exactly as the reference consumes rand(). */
+int mc_randem_initialize(const mc_options *opt, const mc_data *dat, mc_model *mod, mc_rng *rng);
+/* Moves `rng` past n initialisations without performing them: where unit n of a sharded run starts in the serial stream.
+ * A jump for the random allele partition; for Rand-EM and the mixture model the number of draws depends on the draws
+ * themselves (center retries) and on the data (copies that match no center), so the host-side walk is replayed. */
+int mc_skip_initializations(const mc_options *opt, const mc_data *dat, mc_model *mod, mc_rng *rng, int n);
+void mc_init_cache_free(mc_model *mod);
 
 void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod);			/* em_alg.c:44 */
 int mc_em_step(const mc_options *opt, const mc_data *dat, mc_model *mod);		/* em_alg.c:195 */

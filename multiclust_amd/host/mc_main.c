@@ -46,7 +46,8 @@ static void usage(FILE *fp, const char *prog)
 		"  --missing <n> missing-data code (default -9)           -M  print only the maximum log likelihood\n"
 		"  -v [level]    verbosity                                --device <n>  HIP device index\n"
 		"  --gpus <n>    shard the initialisations over n GPUs (admixture; one RCCL all-reduce of the results)\n"
-		"  --streams <n> n concurrent fits per GPU, each on its own stream (small data sets do not fill a GPU)\n", prog);
+		"  --streams <n> n concurrent fits per GPU, each on its own stream (small data sets do not fill a GPU)\n"
+		"  --randem      Rand-EM initialisation: the best of -m <n> (50) candidates from random allele centers\n", prog);
 }
 
 static int arg_int(int argc, const char **argv, int i, long *out)
@@ -131,7 +132,7 @@ static int parse_options(mc_cli_options *o, int argc, const char **argv)
 		case 'k': if (arg_int(argc, argv, ++i, &v) || v < 1) BAD("-k"); o->min_K = o->max_K = (int)v; break;
 		case 'm':
 			if (!strncmp(w, "mi", 2)) { if (arg_int(argc, argv, ++i, &v)) BAD("--missing"); o->missing_value = (int)v; }
-			else { if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-m"); o->n_rand_em_init = (int)v; }	/* stored only */
+			else { if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-m"); o->n_rand_em_init = o->em.n_rand_em_init = (int)v; }
 			break;
 		case 'M': o->parallel = 1; o->n_repeat = 1; o->em.verbosity = MC_SILENT; break;
 		case 'n': if (arg_int(argc, argv, ++i, &v)) BAD("-n"); o->n_init = (int)v; if (!v) o->n_repeat = 0; break;
@@ -143,7 +144,14 @@ static int parse_options(mc_cli_options *o, int argc, const char **argv)
 			break;
 		case 'P': case 'Q': case 'A': BAD("-P/-Q/-A side files are not supported by this build");
 		case 'R': o->R_format = 1; break;
-		case 'r': if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-r"); o->em.seed = (unsigned)v; o->seed_given = 1; break;
+		case 'r':
+			/* extension: --randem selects the Rand-EM initialisation the reference carries but cannot reach
+			 * (initialization_procedure stays NOTHING, multiclust.c:935); -m <n> is its number of candidates */
+			if (!strncmp(w, "ra", 2)) { o->em.initialization_procedure = MC_RAND_EM; break; }
+			if (arg_int(argc, argv, ++i, &v) || v < 0) BAD("-r");
+			o->em.seed = (unsigned)v;
+			o->seed_given = 1;
+			break;
 		case 'x': BAD("-x (block relaxation) is not implemented, as in the reference");
 		case 's':
 			if (!strncmp(w, "si", 2)) BAD("--simulate is not supported by this build");
@@ -330,6 +338,7 @@ typedef struct shard_worker {
 	int K, index, n_dev, n_units, want_params;
 	const mc_simulation *sim;	/* bootstrap replicate generated on the device, or NULL */
 	mc_rng base;			/* the serial stream's state where this K's initialisations begin */
+	mc_rng rng_end;			/* set by the worker that fitted the last unit: the stream after it */
 	uint64_t draws;
 	mc_unit_result *res;		/* [n_units], shared: worker d writes rows u = d, d + n_dev, ... */
 	double best_logL;
@@ -348,9 +357,12 @@ static void *shard_main(void *arg)
 	if ((w->rc = w->sim ? mc_model_create_simulated(&mod, &w->o->em, w->md, w->K, device, w->sim)
 			    : mc_model_create(&mod, &w->o->em, w->md, w->K, device))) return NULL;
 	const clock_t start = clock();
+	/* unit u starts where the serial stream stands after u initialisations: a jump for the random allele partition, a replay
+	 * of the host-side draws for Rand-EM; an initialisation leaves the stream at the next unit's start */
+	mc_rng rng = w->base;
+	if ((w->rc = mc_skip_initializations(&w->o->em, w->md, mod, &rng, w->index))) { mc_model_free(mod); return NULL; }
 	for (int u = w->index; u < w->n_units; u += w->n_dev) {
-		mc_rng rng = w->base;
-		mc_rng_jump(&rng, (uint64_t)u * w->draws);
+		if (u != w->index && (w->rc = mc_skip_initializations(&w->o->em, w->md, mod, &rng, w->n_dev - 1))) break;
 		mc_reset_model_state(mod);
 		mod->start = start;
 		if ((w->rc = mc_initialize_model(&w->o->em, w->md, mod, &rng))) break;
@@ -370,6 +382,7 @@ static void *shard_main(void *arg)
 			w->best_logL = mod->logL;
 			w->best_unit = u;
 		}
+		if (u == w->n_units - 1) w->rng_end = rng;	/* where the serial stream stands after all units */
 	}
 	mc_model_free(mod);
 	return NULL;
@@ -401,7 +414,7 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 	for (int x = 0; x < n_dev; x++) if (th[x]) pthread_join(th[x], NULL);
 	for (int x = 0; x < n_dev; x++) if (w[x].rc) rc = w[x].rc;
 	if (rc) goto DONE;
-	mc_rng_jump(&st->rng, (uint64_t)n_units * w[0].draws);	/* where the serial stream stands after these initialisations */
+	st->rng = w[(n_units - 1) % n_dev].rng_end;	/* where the serial stream stands after these initialisations */
 
 	/* the one exchange: every device's result table holds the rows its workers fitted; an RCCL all-reduce (sum)
 	 * completes them all */
@@ -618,6 +631,7 @@ int main(int argc, const char **argv)
 	if (o.n_bootstrap && o.max_K <= 1) { fprintf(stderr, "ERROR: When bootstrapping, maximum K (%d) (set with command-line argument -k) must exceed 1.\n", o.max_K); return 2; }
 	if (o.min_K > o.max_K) { fprintf(stderr, "ERROR: Minimum K (%d) must not exceed maximum K (%d).\n", o.min_K, o.max_K); return 2; }
 	if (!o.target_ll && !o.target_revisit && !o.em.n_seconds && !o.n_init) o.n_init = 1;
+	if (!o.em.n_rand_em_init) o.em.initialization_procedure = MC_INIT_NOTHING;	/* -m 0 (multiclust.c:1549-1550) */
 	memset(&st, 0, sizeof st);
 	st.out = stdout;
 	mchip_comm *run_comm = NULL;
@@ -670,7 +684,8 @@ int main(int argc, const char **argv)
 		if ((!on_device && !sim) || !st.mle_q) { rc = MCHIP_ERR_ALLOC; goto END; }
 		/* whole replicates per device when there is at least one for each; otherwise (or on one device) the replicates run in
 		 * turn and --gpus shards the initialisations inside each */
-		const int by_replicate = on_device && shardable(&o) && o.n_bootstrap >= n_workers(&o);
+		/* (Rand-EM draws a data-dependent number of values per initialisation: replicate b's place in the stream has no closed form) */
+		const int by_replicate = on_device && shardable(&o) && o.n_bootstrap >= n_workers(&o) && o.em.initialization_procedure != MC_RAND_EM;
 		if (by_replicate && (rc = run_bootstrap_sharded(&o, &d, &md, &st, &ntime))) goto END;
 		for (int b = 0; !by_replicate && b < o.n_bootstrap; b++) {
 			printf("Bootstrap dataset %d (of %d):", b + 1, o.n_bootstrap);

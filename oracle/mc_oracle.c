@@ -603,6 +603,194 @@ void mco_random_initialize_admixture(const mco_data *dat, const mco_options *o, 
 	free(assign);
 }
 
+/* ------------------------------------------------------------------ Rand-EM (rnd_init.c:123-160, 412-444) */
+
+void mco_random_allele_center(const mco_data *dat, int K, mco_rng *g, uint8_t *ilk)
+{
+	/* rnd_init.c:496-583, default mode (L_alleles != NULL, m_start = 0): per locus the center alleles -- every allele slot when
+	 * the locus has fewer than K (the phantom slot of a locus with missing data included: it matches nothing), else K distinct
+	 * slots by rejection -- then every copy in i, a order: the first cluster whose center it carries, else rand() % K */
+	const int I = dat->I, L = dat->L, pl = dat->ploidy;
+	int center[K > 0 ? K : 1];
+	if (K == 1) {
+		memset(ilk, 0, (size_t)I * L * pl);
+		return;
+	}
+	for (int l = 0; l < L; l++) {
+		const int M = dat->ua[l];
+		if (M < K) {
+			for (int k = 0; k < M; k++) center[k] = k;
+			for (int k = M; k < K; k++) center[k] = -1;
+		} else {
+			for (int k = 0; k < K; k++) {
+				int flag;
+				center[k] = mco_rand(g) % M;
+				do {
+					flag = 0;
+					for (int j = 0; j < k; j++)
+						if (center[k] == center[j]) {
+							center[k] = mco_rand(g) % M;
+							flag = 1;
+							break;
+						}
+				} while (flag == 1);
+			}
+		}
+		for (int i = 0; i < I; i++)
+			for (int a = 0; a < pl; a++) {
+				const size_t gi = ((size_t)i * L + l) * pl + a;
+				const uint8_t mm = dat->geno[gi];
+				int flag = 0;
+				for (int k = 0; k < K; k++) {
+					if (center[k] == -1) break;
+					if (mm != MCO_MISSING_IDX && mm == center[k]) {
+						ilk[gi] = (uint8_t)k;
+						flag = 1;
+						break;
+					}
+				}
+				if (!flag) ilk[gi] = (uint8_t)(mco_rand(g) % K);
+			}
+	}
+}
+
+void mco_initialize_parameters_admixture(const mco_data *dat, const mco_options *o, mco_model *m, const uint8_t *ilk)
+{
+	/* rnd_init.c:603-705: eta = (1 + copies assigned to k, missing ones too) / (ploidy L [I] + K); p = (1 + copies of allele m
+	 * assigned to k) / sum over m; no projection */
+	const int I = dat->I, L = dat->L, pl = dat->ploidy, K = m->K, T = dat->T;
+	double *P = m->p[m->tindex], *Q = m->q[m->tindex];
+	if (o->eta_constrained) {
+		const double temp = pl * L * I + K;
+		for (int k = 0; k < K; k++) Q[k] = 1;
+		for (size_t j = 0; j < (size_t)I * L * pl; j++) Q[ilk[j]]++;
+		for (int k = 0; k < K; k++) Q[k] /= temp;
+	} else {
+		const double temp = pl * L + K;
+		for (int i = 0; i < I; i++) {
+			for (int k = 0; k < K; k++) Q[(size_t)i * K + k] = 1;
+			for (int l = 0; l < L; l++)
+				for (int a = 0; a < pl; a++) Q[(size_t)i * K + ilk[((size_t)i * L + l) * pl + a]]++;
+			for (int k = 0; k < K; k++) Q[(size_t)i * K + k] /= temp;
+		}
+	}
+	for (size_t x = 0; x < (size_t)K * T; x++) P[x] = 1.0;
+	for (int i = 0; i < I; i++)
+		for (int l = 0; l < L; l++)
+			for (int a = 0; a < pl; a++) {
+				const size_t gi = ((size_t)i * L + l) * pl + a;
+				const uint8_t mm = dat->geno[gi];
+				if (mm != MCO_MISSING_IDX && mm < dat->ua[l]) P[(size_t)ilk[gi] * T + dat->toff[l] + mm]++;
+			}
+	for (int k = 0; k < K; k++)
+		for (int l = 0; l < L; l++) {
+			double temp = 0;
+			for (int mm = 0; mm < dat->ua[l]; mm++) temp += P[(size_t)k * T + dat->toff[l] + mm];
+			for (int mm = 0; mm < dat->ua[l]; mm++) P[(size_t)k * T + dat->toff[l] + mm] /= temp;
+		}
+}
+
+void mco_random_individual_center(const mco_data *dat, int K, mco_rng *g, int *I_K)
+{
+	/* rnd_init.c:192-259 */
+	const int I = dat->I, T = dat->T;
+	int center[K > 0 ? K : 1];
+	if (K == 1) {
+		for (int i = 0; i < I; i++) I_K[i] = 0;
+		return;
+	}
+	for (int k = 0; k < K; k++) {
+		int flag;
+		center[k] = mco_rand(g) % I;
+		do {
+			flag = 0;
+			for (int j = 0; j < k; j++)
+				if (center[k] == center[j]) {
+					center[k] = mco_rand(g) % I;
+					flag = 1;
+					break;
+				}
+		} while (flag == 1);
+	}
+	for (int i = 0; i < I; i++) {
+		I_K[i] = 0;
+		if (i == center[0]) continue;
+		double min_count_diff = INFINITY;
+		for (int k = 0; k < K; k++) {
+			if (i == center[k]) { I_K[i] = k; break; }
+			double count_diff = 0;
+			for (int c = 0; c < T; c++) count_diff += abs(dat->ilm[(size_t)i * T + c] - dat->ilm[(size_t)center[k] * T + c]);
+			if (count_diff < min_count_diff) { I_K[i] = k; min_count_diff = count_diff; }
+		}
+	}
+}
+
+void mco_initialize_parameters_mixture(const mco_data *dat, mco_model *m, const int *I_K)
+{
+	/* rnd_init.c:268-339, including its loop nest: p[k][l][m] = 1 inside the loop over k, then EVERY individual's count is
+	 * added to its own cluster's entry, so cluster k collects its counts K - k times */
+	const int I = dat->I, L = dat->L, K = m->K, T = dat->T;
+	double *P = m->p[m->tindex], *Q = m->q[m->tindex];
+	for (int k = 0; k < K; k++) Q[k] = 1;
+	for (int i = 0; i < I; i++) Q[I_K[i]]++;
+	for (int k = 0; k < K; k++) Q[k] /= I + K;
+	for (int k = 0; k < K; k++)
+		for (int l = 0; l < L; l++)
+			for (int mm = 0; mm < dat->ua[l]; mm++) {
+				const int c = dat->toff[l] + mm;
+				P[(size_t)k * T + c] = 1.0;
+				for (int i = 0; i < I; i++) {
+					if (dat->ilm[(size_t)i * T + c] == 0) continue;
+					P[(size_t)I_K[i] * T + c] += dat->ilm[(size_t)i * T + c];
+				}
+			}
+	for (int k = 0; k < K; k++)
+		for (int l = 0; l < L; l++) {
+			double temp = 0.0;
+			for (int mm = 0; mm < dat->ua[l]; mm++) temp += P[(size_t)k * T + dat->toff[l] + mm];
+			for (int mm = 0; mm < dat->ua[l]; mm++) P[(size_t)k * T + dat->toff[l] + mm] /= temp;
+		}
+}
+
+double mco_em_e_step(const mco_data *d, const mco_options *o, mco_model *m);
+
+void mco_randem_initialize(const mco_data *dat, const mco_options *o, mco_model *m, mco_rng *g, int n_rand_em_init, double *ll_out)
+{
+	/* randem_initialize_admixture (rnd_init.c:412-444) / randem_initialize_mixture (123-160) */
+	const int n_init = m->K > 1 ? n_rand_em_init : 1;
+	const size_t n = (size_t)dat->I * dat->L * dat->ploidy;
+	double max_logL = -INFINITY;
+	if (o->admixture) {
+		uint8_t *ilk = malloc(n), *best = calloc(n, 1);
+		for (int i = 0; i < n_init; i++) {
+			mco_random_allele_center(dat, m->K, g, ilk);
+			mco_initialize_parameters_admixture(dat, o, m, ilk);
+			const double logL = mco_em_e_step(dat, o, m);
+			if (ll_out) ll_out[i] = logL;
+			if (logL > max_logL) {
+				max_logL = logL;
+				memcpy(best, ilk, n);
+			}
+		}
+		mco_initialize_parameters_admixture(dat, o, m, best);
+		free(ilk); free(best);
+	} else {
+		int *I_K = calloc(dat->I, sizeof(int)), *best = calloc(dat->I, sizeof(int));
+		for (int i = 0; i < n_init; i++) {
+			mco_random_individual_center(dat, m->K, g, I_K);
+			mco_initialize_parameters_mixture(dat, m, I_K);
+			const double logL = mco_em_e_step(dat, o, m);
+			if (ll_out) ll_out[i] = logL;
+			if (logL > max_logL) {
+				max_logL = logL;
+				memcpy(best, I_K, sizeof(int) * dat->I);
+			}
+		}
+		mco_initialize_parameters_mixture(dat, m, best);
+		free(I_K); free(best);
+	}
+}
+
 /* ------------------------------------------------------------------ EM control flow */
 
 /* em_alg.c:163-182 */
@@ -976,4 +1164,21 @@ void mco_maximize_likelihood(const mco_data *d, const mco_options *o, mco_model 
 		}
 		mco_summary_add(o, s, u, m->logL, m->converged, m->n_iter, 0);
 	}
+}
+
+double mco_em_e_step(const mco_data *d, const mco_options *o, mco_model *m)
+{
+	/* em_alg.c:219-233: E, M, E; the second E step's log likelihood (no stop(), no iteration count) */
+	if (o->admixture) {
+		if (o->fused) {
+			em_step_admixture_fused(o, m, 1);
+		} else {
+			e_step_admixture_ref(o, m);
+			m_step_admixture_ref(o, m);
+		}
+	} else {
+		e_step_mixture(m);
+		m_step_mixture(o, m);
+	}
+	return mco_e_step(d, o, m);
 }

@@ -80,6 +80,17 @@ void mco_random_initialize_admixture(const mco_data *d, const mco_options *o, mc
 /* same, from a given assignment assign[I][L][ploidy] (k per allele copy) */
 void mco_initialize_from_partition(const mco_data *d, const mco_options *o, mco_model *m, const uint8_t *assign);
 
+/* Rand-EM (the reference carries it but its command line cannot select it, multiclust.c:935): random_allele_center
+ * (rnd_init.c:496-583) fills ilk[I][L][ploidy]; initialize_parameters_admixture (603-705); random_individual_center (192-259)
+ * fills I_K[I]; initialize_parameters_mixture (268-339); randem_initialize_* (123-160, 412-444) keeps the best of n candidates
+ * scored by em_e_step (em_alg.c:219-233) and writes their log likelihoods to ll_out (may be NULL) */
+void mco_random_allele_center(const mco_data *d, int K, mco_rng *g, uint8_t *ilk);
+void mco_initialize_parameters_admixture(const mco_data *d, const mco_options *o, mco_model *m, const uint8_t *ilk);
+void mco_random_individual_center(const mco_data *d, int K, mco_rng *g, int *I_K);
+void mco_initialize_parameters_mixture(const mco_data *d, mco_model *m, const int *I_K);
+void mco_randem_initialize(const mco_data *d, const mco_options *o, mco_model *m, mco_rng *g, int n_rand_em_init, double *ll_out);
+double mco_em_e_step(const mco_data *d, const mco_options *o, mco_model *m);
+
 /* em_alg.c:195-207: E (findex) + M (tindex) + stop(); returns stop flag */
 int mco_em_step(const mco_data *d, const mco_options *o, mco_model *m);
 /* E step only (findex): returns logL, refreshes sik */

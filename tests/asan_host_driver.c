@@ -7,6 +7,8 @@
 /* stubs for the device calls the linked objects reference (never reached here) */
 int mchip_create(mchip_context **c, int d){(void)c;(void)d;return 2;}
 int mchip_destroy(mchip_context *c){(void)c;return 0;}
+int mchip_init_from_allele_centers(mchip_context *c,const uint8_t*a,const uint64_t*b,const uint32_t*w,uint64_t n,int t){(void)c;(void)a;(void)b;(void)w;(void)n;(void)t;return 2;}
+int mchip_copy_slot(mchip_context *c,int a,int b){(void)c;(void)a;(void)b;return 2;}
 const char *mchip_last_error(const mchip_context *c){(void)c;return "";}
 int mchip_set_genotypes(mchip_context *c,int a,int b,int d,const int32_t*u,const uint8_t*g){(void)c;(void)a;(void)b;(void)d;(void)u;(void)g;return 2;}
 int mchip_set_model(mchip_context *c,int a,int b,int d,int e,double f,double g,int h){(void)c;(void)a;(void)b;(void)d;(void)e;(void)f;(void)g;(void)h;return 2;}
@@ -49,6 +51,18 @@ int main(int argc, char **argv)
 			mc_partition(&d, &fv, NULL, cnt);
 			mc_write_results(&o, &d, &fv, cnt);
 			free(q); free(p); free(s);
+			/* the host-side walks of Rand-EM (allele-count table, center draws, unmatched-copy counts) and of the mixture
+			 * model's random centers: skipping initialisations touches no device */
+			for (int admix = 0; admix < 2; admix++)
+				for (int KK = 1; KK <= 5; KK += 2) {
+					mc_options ro; mc_make_options(&ro);
+					ro.admixture = admix; ro.initialization_procedure = MC_RAND_EM; ro.n_rand_em_init = 3;
+					mc_data md = { d.I, d.L, d.ploidy, d.uniquealleles, d.geno, NULL };
+					mc_model mm; memset(&mm, 0, sizeof mm); mm.K = KK;
+					mc_rng rg; mc_srand(&rg, 11);
+					if (mc_skip_initializations(&ro, &md, &mm, &rg, 2)) return 3;
+					mc_init_cache_free(&mm);
+				}
 			mc_free_data(&d);
 		}
 	}

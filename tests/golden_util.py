@@ -9,6 +9,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 ADMIX_CASES = ["c1_admix_k3", "multi_admix_k4", "tetra_admix_k3", "missing_admix_k3"]
 ALL_CASES = sorted(d for d in os.listdir(GOLD) if os.path.exists(os.path.join(GOLD, d, "q0.f64")))     # full EM fixtures
+RANDEM_CASES = [d for d in ALL_CASES if os.path.exists(os.path.join(GOLD, d, "randem_ll.f64"))]                # Rand-EM dumps
 ACCEL_CASES = [d for d in ALL_CASES if os.path.exists(os.path.join(GOLD, d, "accel_trace.f64"))]         # -s 1..6 given
 
 

@@ -62,6 +62,11 @@ def _load():
     lib.mco_michelot_project.argtypes = [dp, i32, C.c_double, C.c_double]
     lib.mco_random_initialize_admixture.argtypes = [vp, C.POINTER(Options), vp, C.POINTER(Rng)]
     lib.mco_initialize_from_partition.argtypes = [vp, C.POINTER(Options), vp, vp]
+    lib.mco_randem_initialize.argtypes = [vp, C.POINTER(Options), vp, C.POINTER(Rng), i32, dp]
+    lib.mco_random_allele_center.argtypes = [vp, i32, C.POINTER(Rng), vp]
+    lib.mco_initialize_parameters_admixture.argtypes = [vp, C.POINTER(Options), vp, vp]
+    lib.mco_em_e_step.argtypes = [vp, C.POINTER(Options), vp]
+    lib.mco_em_e_step.restype = C.c_double
     lib.mco_em_step.argtypes = [vp, C.POINTER(Options), vp]
     lib.mco_em_step.restype = i32
     lib.mco_e_step.argtypes = [vp, C.POINTER(Options), vp]
@@ -139,6 +144,14 @@ class Model:
         lib.mco_srand(C.byref(rng), seed)
         lib.mco_random_initialize_admixture(self.data.h, C.byref(self.opt), self.h, C.byref(rng))
         return rng
+
+    def init_randem(self, seed, n_candidates):
+        """Rand-EM initialisation from srand(seed); returns (generator afterwards, per-candidate log likelihoods)"""
+        rng = Rng()
+        lib.mco_srand(C.byref(rng), seed)
+        ll = np.zeros(max(1, n_candidates))
+        lib.mco_randem_initialize(self.data.h, C.byref(self.opt), self.h, C.byref(rng), n_candidates, ll.ctypes.data_as(C.POINTER(C.c_double)))
+        return rng, ll
 
     def init_from_partition(self, assign):
         a = np.ascontiguousarray(assign, dtype=np.uint8)

@@ -14,7 +14,7 @@ def test_host_c_code_is_sanitizer_clean(tmp_path):
     exe = str(tmp_path / "asan_host")
     host = os.path.join(ROOT, "multiclust_amd", "host")
     srcs = [os.path.join(ROOT, "tests", "asan_host_driver.c")] + [os.path.join(host, f) for f in
-                                                                  ("mc_reader.c", "mc_writer.c", "mc_fit.c", "mc_em.c")]
+                                                                  ("mc_reader.c", "mc_writer.c", "mc_fit.c", "mc_em.c", "mc_init.c")]
     subprocess.run(["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
                     "-I" + os.path.join(ROOT, "include"), "-I" + host, "-o", exe] + srcs + ["-lm", "-lpthread"], check=True)
     data = os.path.join(ROOT, "tests", "golden", "data")

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_bind as ob
-from golden_util import ACCEL_CASES, ALL_CASES, Golden, ulp_diff
+from golden_util import ACCEL_CASES, ALL_CASES, RANDEM_CASES, Golden, ulp_diff
 
 
 def make(g, fused=0, **kw):
@@ -232,3 +232,38 @@ def test_squarem_path_depends_on_summation_order(name):
     assert abs(mod.n_iter - g.m["accel_run_n_iter"]) <= max(8, g.m["accel_run_n_iter"] // 4)
     assert 1e-8 < abs(mod.logL - g.m["accel_run_logL"]) <= 5e-2          # not reproducible to north_star's 1e-8, by construction
     assert np.abs(mod.q(mod.pindex) - g.q("accelrun")).max() <= 2e-2
+
+
+@pytest.mark.parametrize("name", RANDEM_CASES)
+def test_randem_initialisation(name):
+    """Rand-EM (rnd_init.c:123-160, 412-444, 496-705) against the reference's own routine, driven by the harness with
+    initialization_procedure = RAND_EM: per-candidate log likelihoods, the parameters it settles on, the position of the
+    rand() stream afterwards, and the fit em() reaches from there -- bit for bit."""
+    g = Golden(name)
+    opt, data, mod = make(g, abs_error=g.m["abs_error"], rel_error=g.m["rel_error"])
+    n = g.m["randem_candidates"]
+    rng, ll = mod.init_randem(g.m["seed"], n)
+    assert np.array_equal(ll[:n], g.f64("randem_ll.f64"))
+    assert int(np.argmax(ll[:n])) == g.m["randem_best"]
+    assert ob.lib.mco_rand(rng) == g.m["rand_after_randem"]
+    assert np.array_equal(mod.q(0), g.q("randem"))
+    assert np.array_equal(mod.p(0), g.p("randem"))
+    mod.em()
+    assert mod.n_iter == g.m["randem_run_n_iter"] and mod.converged == g.m["randem_run_converged"]
+    assert mod.logL == g.m["randem_run_logL"]
+    assert np.array_equal(mod.q(mod.pindex), g.q("randemrun"))
+    assert np.array_equal(mod.p(mod.pindex), g.p("randemrun"))
+
+
+@pytest.mark.parametrize("name", [n for n in RANDEM_CASES if Golden(n).m["admixture"]])
+def test_randem_first_candidate_parameters(name):
+    """random_allele_center + initialize_parameters_admixture of the first candidate (before its EM iteration)"""
+    g = Golden(name)
+    opt, data, mod = make(g)
+    rng = ob.Rng()
+    ob.lib.mco_srand(rng, g.m["seed"])
+    ilk = np.zeros(g.I * g.L * g.ploidy, dtype=np.uint8)
+    ob.lib.mco_random_allele_center(data.h, g.K, rng, ilk.ctypes.data)
+    ob.lib.mco_initialize_parameters_admixture(data.h, opt, mod.h, ilk.ctypes.data)
+    assert np.array_equal(mod.q(0), g.q("randem_c0"))
+    assert np.array_equal(mod.p(0), g.p("randem_c0"))
