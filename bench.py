@@ -80,7 +80,13 @@ def launch_ranks(n):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.call(cmd))
+    # the ranks' stdout is passed on line by line: the one JSON line to stdout, anything else a library printed there (gloo's
+    # connection banner in rehearsals) to stderr
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line)
+        sys.stdout.flush()
+    sys.exit(proc.wait())
 
 
 class Env:
@@ -456,13 +462,19 @@ def run_bootstrap(env, w, ua, geno, n_rep, budget, n_init=1):
     env.barrier()
     t0 = time.perf_counter()
     rows = np.zeros((n_rep, 5))
+    models = (C.POINTER(host.McModel) * 2)()              # this rank's K-1 and K models, re-used by every replicate
     for b in mine:
         r = host.McReplicateResult()
         rc = lib.mc_fit_replicate(C.byref(opt), C.byref(dat), env.local_rank, C.byref(base), b, K0, K1, n_init, K0,
-                                  mle_q.ctypes.data, mle_p.ctypes.data, C.byref(r))
+                                  mle_q.ctypes.data, mle_p.ctypes.data, C.byref(r), models)
         if rc or r.fatal:
             raise SystemExit("replicate %d: rc=%d fatal=%d" % (b, rc, r.fatal))
         rows[b] = (r.ts, r.logL_H0, r.logL_HA, r.n_iter, 1.0)
+        if os.environ.get("MC_TIMING"):
+            sys.stderr.write("replicate %d done %.3f s after the start\n" % (b, time.perf_counter() - t0))
+    for mp in models:
+        if mp:
+            lib.mc_model_free(mp)
     flat = env.reduce(rows.ravel().tolist(), "SUM")         # the one exchange: disjoint rows
     rows = np.array(flat).reshape(n_rep, 5)
     env.barrier()

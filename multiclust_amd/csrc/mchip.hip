@@ -40,6 +40,11 @@ struct mchip_context {
 	int n_cu;
 	/* data set */
 	int I, L, ploidy, T, max_M;
+	std::vector<int32_t> h_ua;	/* host copy of uniquealleles: a data set of the same shape reuses every buffer */
+	int parked_K;			/* model buffers kept allocated for this K (and the signature below) while no model is set */
+	int sig_admixture, sig_constrained, sig_projection, sig_nsec;
+	double sig_eta_lb, sig_p_lb;
+	int init_geno_set;		/* d_initA / d_initS hold the observed haplotypes (mchip_set_init_genotypes) */
 	int32_t *d_ua, *d_toff, *d_col_locus;
 	uint8_t *d_col_allele;
 	uint8_t *d_gtA, *d_gtS, *d_gtC;
@@ -721,18 +726,25 @@ static void prof_mark(mchip_context *ctx, int kind, bool start)
 	if (start) ctx->ev_kind.push_back(kind);
 }
 
-static void free_model(mchip_context *ctx)
+/* the captured steps carry their kernel arguments by value (buffer addresses, the data set's has_missing flag) */
+static void drop_graphs(mchip_context *ctx)
 {
 	for (int s = 0; s < 3; s++)
 		if (ctx->step_graph[s]) { (void)hipGraphExecDestroy(ctx->step_graph[s]); ctx->step_graph[s] = nullptr; }
 	for (int s = 0; s < 3; s++)
 		for (int m = 0; m < 5; m++)
 			if (ctx->cycle_graph[s][m]) { (void)hipGraphExecDestroy(ctx->cycle_graph[s][m]); ctx->cycle_graph[s][m] = nullptr; }
+}
+
+static void free_model(mchip_context *ctx)
+{
+	drop_graphs(ctx);
 	for (int s = 0; s < 3; s++) { dfree(ctx->d_p[s]); dfree(ctx->d_q[s]); }
 	for (int s = 0; s < MCHIP_MAX_SECANTS; s++) { dfree(ctx->d_up[s]); dfree(ctx->d_vp[s]); dfree(ctx->d_uq[s]); dfree(ctx->d_vq[s]); }
 	dfree(ctx->d_sik); dfree(ctx->d_stage); dfree(ctx->d_logp); dfree(ctx->d_ssum); dfree(ctx->d_Apart); dfree(ctx->d_Spart); dfree(ctx->d_llpart);
 	dfree(ctx->d_redpart); dfree(ctx->d_flags);
 	ctx->K = 0;
+	ctx->parked_K = 0;
 	ctx->kt = nullptr;
 	ctx->have_ll = 0;
 	ctx->s_cache_slot = -1;
@@ -745,6 +757,8 @@ static void free_data(mchip_context *ctx)
 	dfree(ctx->d_initA); dfree(ctx->d_initS);
 	dfree(ctx->d_draw); dfree(ctx->d_jump_hi); dfree(ctx->d_jump_lo);
 	ctx->n_jump_hi = 0;
+	ctx->init_geno_set = 0;
+	ctx->h_ua.clear();
 	ctx->I = ctx->L = ctx->T = 0;
 }
 
@@ -851,12 +865,25 @@ int mchip_device_info(mchip_context *ctx, char *name, int name_len, int *compute
 }
 
 /* shape of a data set: tables derived from uniquealleles, genotype buffers allocated but not filled */
-static int set_shape(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua)
+static int set_shape(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, int keep_init = 0)
 {
 	if (I <= 0 || L <= 0 || ploidy <= 0 || ploidy > 64 || !ua)
 		return fail(ctx, MCHIP_ERR_INVALID, "set_genotypes: bad shape or null pointer%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
+	/* The same shape and allele lists as the data set held (the next bootstrap replicate, a re-upload): every buffer stays;
+	 * the model is dropped as the contract says, but its buffers are parked for an mchip_set_model with the same arguments.
+	 * Freeing and re-allocating ~10 GB per replicate costs little per call, but the runtime returns freed memory lazily and
+	 * stalls for seconds once the card's memory has been through its hands (measured: every 11th config-5 replicate) */
+	if (ctx->T && ctx->I == I && ctx->L == L && ctx->ploidy == ploidy && (int)ctx->h_ua.size() == L &&
+	    !memcmp(ctx->h_ua.data(), ua, sizeof(int32_t) * (size_t)L)) {
+		if (ctx->K) ctx->parked_K = ctx->K;
+		ctx->K = 0;
+		ctx->have_ll = 0;
+		ctx->s_cache_slot = -1;
+		if (!keep_init) ctx->init_geno_set = 0;
+		return MCHIP_OK;
+	}
 	free_model(ctx);	/* workspaces depend on T */
 	free_data(ctx);
 
@@ -880,6 +907,7 @@ static int set_shape(mchip_context *ctx, int I, int L, int ploidy, const int32_t
 			col_allele[toff[l] + m] = (uint8_t)m;
 		}
 	ctx->I = I; ctx->L = L; ctx->ploidy = ploidy; ctx->T = T; ctx->max_M = maxM;
+	ctx->h_ua.assign(ua, ua + L);
 	ctx->geno_bytes_A = (size_t)((I + 7) / 8) * L * 8 * ploidy;
 	ctx->geno_bytes_S = (size_t)((L + 7) / 8) * I * 8 * ploidy;
 	HIPCHK(hipMalloc((void **)&ctx->d_ua, sizeof(int32_t) * L));
@@ -893,6 +921,16 @@ static int set_shape(mchip_context *ctx, int I, int L, int ploidy, const int32_t
 	HIPCHK(hipMemcpyAsync(ctx->d_col_locus, col_locus.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(ctx->d_col_allele, col_allele.data(), T, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));	/* the host vectors go out of scope */
+	return MCHIP_OK;
+}
+
+/* one byte per allele copy in stream order, padded to whole generator chunks: the device-drawn partition, a generated data
+ * set before it goes into the kernels' layouts, an uploaded genotype on its way there.  Kept for the life of the data set. */
+static int stream_buffer(mchip_context *ctx)
+{
+	if (ctx->d_draw) return MCHIP_OK;
+	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
+	HIPCHK(hipMalloc((void **)&ctx->d_draw, ((n + RNG_CHUNK - 1) / RNG_CHUNK) * RNG_CHUNK));
 	return MCHIP_OK;
 }
 
@@ -913,6 +951,7 @@ static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
 		free_data(ctx);
 		return fail(ctx, MCHIP_ERR_INVALID, "genotype allele index >= uniquealleles[l]%s", nullptr);
 	}
+	if (ctx->has_missing != ((bad & 2) ? 1 : 0)) drop_graphs(ctx);	/* parked model buffers: the kernel variant changes */
 	ctx->has_missing = (bad & 2) ? 1 : 0;
 	{	/* non-empty cells and allele copies of the data set (integer sums: order does not matter) */
 		unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(ctx->d_scalars + 60), h_cnt[2] = {0, 0};
@@ -952,10 +991,9 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	int rc = set_shape(ctx, I, L, ploidy, ua);
 	if (rc) return rc;
 	const size_t raw_bytes = (size_t)I * L * ploidy;
-	scoped_dev<uint8_t> d_raw;
-	HIPCHK(d_raw.alloc(raw_bytes));
-	HIPCHK(hipMemcpyAsync(d_raw, geno, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
-	return install_raw(ctx, d_raw);
+	if ((rc = stream_buffer(ctx))) return rc;
+	HIPCHK(hipMemcpyAsync(ctx->d_draw, geno, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
+	return install_raw(ctx, ctx->d_draw);
 }
 
 int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
@@ -964,19 +1002,23 @@ int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
 	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "no genotypes set%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
-	dfree(ctx->d_initA);
-	dfree(ctx->d_initS);
-	if (!geno) return MCHIP_OK;
+	ctx->init_geno_set = 0;
+	if (!geno) {
+		dfree(ctx->d_initA);
+		dfree(ctx->d_initS);
+		return MCHIP_OK;
+	}
 	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
-	scoped_dev<uint8_t> d_obs;
 	int *d_bad = bad_flag(ctx);
-	HIPCHK(d_obs.alloc(n));
-	HIPCHK(hipMalloc((void **)&ctx->d_initA, ctx->geno_bytes_A));
-	HIPCHK(hipMalloc((void **)&ctx->d_initS, ctx->geno_bytes_S));
+	int rc = stream_buffer(ctx);
+	if (rc) return rc;
+	uint8_t *d_obs = ctx->d_draw;
+	if (!ctx->d_initA) HIPCHK(hipMalloc((void **)&ctx->d_initA, ctx->geno_bytes_A));
+	if (!ctx->d_initS) HIPCHK(hipMalloc((void **)&ctx->d_initS, ctx->geno_bytes_S));
 	HIPCHK(hipMemcpyAsync(d_obs, geno, n, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
-	hipLaunchKernelGGL(k_relayout, dim3(nblk_capped(nmax)), dim3(256), 0, ctx->stream, d_obs.p, ctx->I, ctx->L, ctx->ploidy, ctx->d_ua, 0,
+	hipLaunchKernelGGL(k_relayout, dim3(nblk_capped(nmax)), dim3(256), 0, ctx->stream, d_obs, ctx->I, ctx->L, ctx->ploidy, ctx->d_ua, 0,
 			   ctx->d_initA, ctx->d_initS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
@@ -987,6 +1029,7 @@ int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
 		dfree(ctx->d_initS);
 		return fail(ctx, MCHIP_ERR_INVALID, "init genotype allele index >= uniquealleles[l]%s", nullptr);
 	}
+	ctx->init_geno_set = 1;
 	return MCHIP_OK;
 }
 
@@ -1027,7 +1070,27 @@ int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constraine
 		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "K*T or K*I of 2^31 or more is not supported%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
+	{	/* the buffers of this very model are still allocated (same data shape, same arguments): zero the parameters and go */
+		const int have = ctx->K ? ctx->K : ctx->parked_K;
+		if (have == K && ctx->d_p[0] && ctx->sig_admixture == admixture && ctx->sig_constrained == (eta_constrained ? 1 : 0) &&
+		    ctx->sig_projection == do_projection && ctx->sig_nsec == n_secants && ctx->sig_eta_lb == eta_lb && ctx->sig_p_lb == p_lb) {
+			const size_t KTr = (size_t)K * ctx->T;
+			for (int s = 0; s < 3; s++) {
+				HIPCHK(hipMemsetAsync(ctx->d_p[s], 0, KTr * sizeof(double), ctx->stream));
+				HIPCHK(hipMemsetAsync(ctx->d_q[s], 0, (size_t)ctx->nq * sizeof(double), ctx->stream));
+			}
+			HIPCHK(hipMemsetAsync(ctx->d_sik, 0, (size_t)ctx->I * K * sizeof(double), ctx->stream));
+			ctx->K = K;
+			ctx->parked_K = 0;
+			ctx->have_ll = 0;
+			ctx->s_cache_slot = -1;
+			HIPCHK(hipStreamSynchronize(ctx->stream));
+			return MCHIP_OK;
+		}
+	}
 	free_model(ctx);
+	ctx->sig_admixture = admixture; ctx->sig_constrained = eta_constrained ? 1 : 0; ctx->sig_projection = do_projection;
+	ctx->sig_nsec = n_secants; ctx->sig_eta_lb = eta_lb; ctx->sig_p_lb = p_lb;
 	ctx->K = K; ctx->admixture = admixture; ctx->constrained = eta_constrained ? 1 : 0;
 	ctx->do_projection = do_projection; ctx->eta_lb = eta_lb; ctx->p_lb = p_lb; ctx->nsec = n_secants;
 	ctx->kt = mchip_get_ktable(K);
@@ -1419,7 +1482,7 @@ static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to, int
 	if (bad) return fail(ctx, MCHIP_ERR_INVALID, "partition assignment >= K%s", nullptr);
 
 	mchip_pass_args a = pass_args(ctx, to);
-	if (ctx->d_initA) {	/* bootstrap fits: the partition indicators come from the observed haplotypes (rnd_init.c:471) */
+	if (ctx->init_geno_set) {	/* bootstrap fits: the partition indicators come from the observed haplotypes (rnd_init.c:471) */
 		a.gtA = ctx->d_initA;
 		a.gtS = ctx->d_initS;
 	}
@@ -1529,7 +1592,7 @@ int mchip_mstep_from_rand_partition(mchip_context *ctx, const uint32_t *window, 
 	rng_window base;
 	size_t n_chunks, n_blocks;
 	if ((rc = rng_stream_setup(ctx, window, n, &base, &n_chunks, &n_blocks))) return rc;
-	if (!ctx->d_draw) HIPCHK(hipMalloc((void **)&ctx->d_draw, n_chunks * RNG_CHUNK));
+	if ((rc = stream_buffer(ctx))) return rc;
 	if (ctx->K == 1) {
 		HIPCHK(hipMemsetAsync(ctx->d_draw, 0, n, ctx->stream));	/* rand() % 1 */
 	} else {
@@ -1584,7 +1647,7 @@ int mchip_init_from_allele_centers(mchip_context *ctx, const uint8_t *centers, c
 	HIPCHK(hipMemcpyAsync(d_cen, centers, (size_t)ctx->L * ctx->K, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(d_off, draw_offset, sizeof(uint64_t) * (size_t)ctx->L, hipMemcpyHostToDevice, ctx->stream));
 	hipLaunchKernelGGL(k_assign_by_centers, dim3(nblk((size_t)ctx->L)), dim3(256), 0, ctx->stream,
-			   ctx->d_initA ? ctx->d_initA : ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, ctx->K, d_cen.p, d_off.p, d_span.p, d_raw.p);
+			   ctx->init_geno_set ? ctx->d_initA : ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, ctx->K, d_cen.p, d_off.p, d_span.p, d_raw.p);
 	HIPCHK(hipGetLastError());
 	rc = partition_mstep(ctx, d_raw, to, 1);
 	(void)hipStreamSynchronize(ctx->stream);	/* the temporaries go out of scope */
@@ -1608,7 +1671,9 @@ int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const
 {
 	if (!ctx) return MCHIP_ERR_INVALID;
 	if (!window || !q || !p || K < 1) return fail(ctx, MCHIP_ERR_INVALID, "simulate_genotypes: null pointer or K < 1%s", nullptr);
-	int rc = set_shape(ctx, I, L, ploidy, ua);
+	/* a replicate of the same observed data: the observed haplotypes installed by mchip_set_init_genotypes stay in force
+	 * (the reference's dat->IL stays in place across parametric_bootstrap calls, bootstrap.c:35-41) */
+	int rc = set_shape(ctx, I, L, ploidy, ua, 1);
 	if (rc) return rc;
 	const size_t n_copies = (size_t)I * L * ploidy;
 	rng_window base;
@@ -1616,15 +1681,15 @@ int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const
 	if ((rc = rng_stream_setup(ctx, window, 2 * n_copies, &base, &n_chunks, &n_blocks))) return rc;
 	const size_t nq = eta_constrained ? (size_t)K : (size_t)I * K, np = (size_t)K * ctx->T;
 	scoped_dev<double> d_q, d_p;
-	scoped_dev<uint8_t> d_raw;
 	HIPCHK(d_q.alloc(nq));
 	HIPCHK(d_p.alloc(np));
-	HIPCHK(d_raw.alloc(n_chunks * (RNG_CHUNK / 2)));
+	if ((rc = stream_buffer(ctx))) return rc;	/* n_chunks * RNG_CHUNK / 2 <= its size */
+	uint8_t *d_raw = ctx->d_draw;
 	HIPCHK(hipMemcpyAsync(d_q, q, nq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(d_p, p, np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	hipLaunchKernelGGL(k_simulate_admixture, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, base, ctx->d_jump_hi,
 			   ctx->d_jump_lo, n_chunks, n_copies, L, ploidy, K, ctx->T, ctx->d_toff, d_q.p, eta_constrained ? 0 : K, d_p.p,
-			   (uint32_t *)d_raw.p);
+			   (uint32_t *)d_raw);
 	HIPCHK(hipGetLastError());
 	rc = install_raw(ctx, d_raw);
 	(void)hipStreamSynchronize(ctx->stream);	/* the temporaries go out of scope */

@@ -114,7 +114,7 @@ def load():
     lib.mc_model_create_simulated.argtypes = [C.POINTER(MP), OP, DP, C.c_int, C.c_int, C.POINTER(McSimulation)]
     lib.mc_model_get_genotypes.argtypes = [MP, C.c_void_p]
     lib.mc_fit_replicate.argtypes = [OP, DP, C.c_int, C.POINTER(McRng), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_void_p, C.c_void_p, C.POINTER(McReplicateResult)]
+                                     C.c_void_p, C.c_void_p, C.POINTER(McReplicateResult), C.POINTER(MP)]
     lib.mc_aic.restype = C.c_double
     lib.mc_aic.argtypes = [C.c_double, C.c_int]
     lib.mc_bic.restype = C.c_double

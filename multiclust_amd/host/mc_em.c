@@ -159,6 +159,21 @@ int mc_model_create_simulated(mc_model **out, const mc_options *opt, const mc_da
 	return model_create(out, opt, dat, K, device, sim);
 }
 
+/* The next bootstrap replicate into a model that already holds one of the same observed data set (same K, same options):
+ * the device keeps every buffer and the observed haplotypes the initialisation reads; only the data set is generated anew. */
+int mc_model_resimulate(mc_model *mod, const mc_options *opt, const mc_data *dat, const mc_simulation *sim)
+{
+	int rc;
+	if (!mod || !sim || !opt->admixture) return MCHIP_ERR_INVALID;
+	rc = mchip_simulate_genotypes(mod->dev, dat->I, dat->L, dat->ploidy, dat->uniquealleles, sim->window, sim->K,
+				      opt->eta_constrained, sim->q, sim->p);
+	if (!rc) rc = mchip_set_model(mod->dev, mod->K, opt->admixture, opt->eta_constrained, opt->do_projection,
+				      opt->eta_lower_bound, opt->p_lower_bound, opt->accel_scheme ? opt->q : 0);
+	if (rc) fprintf(stderr, "ERROR [mc_em.c::mc_model_resimulate]: %s\n", mchip_last_error(mod->dev));
+	mc_reset_model_state(mod);
+	return rc;
+}
+
 int mc_model_get_genotypes(mc_model *mod, uint8_t *geno) { return mchip_get_genotypes(mod->dev, geno); }
 
 /* ------------------------------------------------------------------ parametric bootstrap (bootstrap.c:76-175)

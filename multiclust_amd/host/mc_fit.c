@@ -7,7 +7,16 @@
 #include "mc_host.h"
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+static double now_ms(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 
 /* ------------------------------------------------------------------ rand() jump-ahead */
 static void polymul_mod(const uint32_t *a, const uint32_t *b, uint32_t *out)
@@ -129,7 +138,7 @@ int mc_fit_unit(const mc_options *opt, const mc_data *dat, mc_model *mod, unsign
  * model are fitted to it (only one when K = 1, multiclust.c:630), each from the stream where the serial program would be;
  * the test statistic is the difference of the two best log likelihoods. */
 int mc_fit_replicate(const mc_options *opt, const mc_data *dat, int device, const mc_rng *base, int b, int null_K, int alt_K,
-		     int n_init, int mle_K, const double *mle_q, const double *mle_p, mc_replicate_result *out)
+		     int n_init, int mle_K, const double *mle_q, const double *mle_p, mc_replicate_result *out, mc_model **models)
 {
 	const uint64_t per_init = mc_draws_per_init(opt, dat, alt_K);
 	const uint64_t units0 = null_K == 1 ? 1 : (uint64_t)n_init, units1 = alt_K == 1 ? 1 : (uint64_t)n_init;
@@ -148,18 +157,33 @@ int mc_fit_replicate(const mc_options *opt, const mc_data *dat, int device, cons
 		const uint64_t units = h ? units1 : units0;
 		double best = -INFINITY;
 		mc_model *mod = NULL;
-		if ((rc = mc_model_create_simulated(&mod, opt, dat, K, device, &gen))) break;
+		const int timing = getenv("MC_TIMING") != NULL;	/* diagnostics: where a replicate spends its time */
+		double t0 = timing ? now_ms() : 0, t1, t2, t3;
+		if (models && models[h]) {
+			mod = models[h];
+			if ((rc = mc_model_resimulate(mod, opt, dat, &gen))) break;
+		} else {
+			if ((rc = mc_model_create_simulated(&mod, opt, dat, K, device, &gen))) break;
+			if (models) models[h] = mod;
+		}
+		t1 = timing ? now_ms() : 0;
 		for (uint64_t u = 0; u < units; u++) {
 			const int delta_keep = mod->delta_index;
 			mc_reset_model_state(mod);
 			mod->delta_index = delta_keep;
 			if ((rc = mc_initialize_model(opt, dat, mod, &rng))) break;
+			t2 = timing ? now_ms() : 0;
 			mc_em(opt, dat, mod);
+			t3 = timing ? now_ms() : 0;
+			if (timing) fprintf(stderr, "replicate %d K=%d unit %d: create+generate %.1f ms, initialise %.1f ms, em (%d iterations) %.1f ms\n",
+					    b, K, (int)u, t1 - t0, t2 - t1, mod->n_iter, t3 - t2);
 			out->n_iter += mod->n_iter;
 			if (mod->fatal) { out->fatal = mod->fatal; break; }
 			if (mod->logL > best) best = mod->logL;
 		}
-		mc_model_free(mod);
+		t2 = timing ? now_ms() : 0;
+		if (!models) mc_model_free(mod);
+		if (timing) fprintf(stderr, "replicate %d K=%d: model freed in %.1f ms, %.1f ms since the model was requested\n", b, K, now_ms() - t2, now_ms() - t0);
 		if (h) out->logL_HA = best; else out->logL_H0 = best;
 	}
 	out->ts = out->logL_HA - out->logL_H0;

@@ -107,6 +107,7 @@ void mc_simulation_begin(mc_simulation *sim, const mc_options *opt, const mc_dat
 			 const double *p, mc_rng *rng);
 int mc_model_create_simulated(mc_model **mod, const mc_options *opt, const mc_data *dat, int K, int device,
 			      const mc_simulation *sim);
+int mc_model_resimulate(mc_model *mod, const mc_options *opt, const mc_data *dat, const mc_simulation *sim);
 int mc_model_get_genotypes(mc_model *mod, uint8_t *geno);
 const char *mc_model_error(const mc_model *mod);
 int mc_model_set_p(mc_model *mod, int slot, const double *p);
@@ -175,8 +176,10 @@ typedef struct mc_replicate_result {
 	int n_iter;			/* EM iterations of all fits of the replicate */
 	int fatal;
 } mc_replicate_result;
+/* models[2] (may be NULL): the caller's null_K and alt_K models, created on first use and re-used for every later replicate
+ * (free them with mc_model_free when the replicates are done); NULL: models are created and freed inside the call */
 int mc_fit_replicate(const mc_options *opt, const mc_data *dat, int device, const mc_rng *base, int b, int null_K, int alt_K,
-		     int n_init, int mle_K, const double *mle_q, const double *mle_p, mc_replicate_result *out);
+		     int n_init, int mle_K, const double *mle_q, const double *mle_p, mc_replicate_result *out, mc_model **models);
 
 #ifdef __cplusplus
 }

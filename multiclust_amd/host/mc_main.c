@@ -207,6 +207,8 @@ typedef struct run_state {
 	mc_rng rng;
 	FILE *out;			/* stdout, or a replicate's buffer when bootstrap replicates run on several devices */
 	mchip_comm **comm;		/* the run's RCCL communicator over devices device..device+n_gpus-1, created on first use */
+	mc_model **sim_models;		/* [2] or NULL: this worker's H0 / HA models of the bootstrap data sets, kept from one replicate to
+					 * the next (same shape, same K: the device re-uses every buffer, mc_model_resimulate) */
 } run_state;
 
 /* sharded runs use n_gpus * n_streams workers (host thread + context + stream each); worker x sits on device
@@ -495,10 +497,17 @@ static int estimate_model(const mc_cli_options *o, const mc_cli_data *d, const m
 			rc = maximize_likelihood_sharded(o, d, md, K, st, bootstrap, sim);
 		} else {
 			mc_model *mod = NULL;
-			if ((rc = sim ? mc_model_create_simulated(&mod, &o->em, md, K, o->device, sim)
-				      : mc_model_create(&mod, &o->em, md, K, o->device))) return rc;
+			mc_model **slot = (sim && st->sim_models) ? &st->sim_models[K == st->alt_K ? 1 : 0] : NULL;
+			if (slot && *slot && (*slot)->K == K) {
+				mod = *slot;
+				if ((rc = mc_model_resimulate(mod, &o->em, md, sim))) return rc;
+			} else {
+				if ((rc = sim ? mc_model_create_simulated(&mod, &o->em, md, K, o->device, sim)
+					      : mc_model_create(&mod, &o->em, md, K, o->device))) return rc;
+				if (slot) { mc_model_free(*slot); *slot = mod; }
+			}
 			rc = maximize_likelihood(o, d, md, mod, st, bootstrap);
-			mc_model_free(mod);
+			if (!slot) mc_model_free(mod);
 		}
 		if (rc) return rc;
 		if (o->n_repeat == 1 && o->em.verbosity)
@@ -547,8 +556,10 @@ static void *bs_main(void *arg)
 	ow.device = worker_device(w->o, w->index);
 	ow.n_gpus = 0;			/* the fits of a replicate stay on this device, on this worker's stream */
 	ow.n_streams = 1;
+	mc_model *kept[2] = { NULL, NULL };
 	for (int b = w->index; b < w->o->n_bootstrap; b += w->n_dev) {
 		run_state ls = *w->st;
+		ls.sim_models = kept;
 		mc_simulation gen;
 		size_t len = 0;
 		ls.mle_q = w->st->mle_q; ls.mle_p = w->st->mle_p;	/* read only */
@@ -558,9 +569,11 @@ static void *bs_main(void *arg)
 		mc_simulation_begin(&gen, &ow.em, w->md, ls.mle_K, ls.mle_q, ls.mle_p, &ls.rng);
 		w->rc = estimate_model(&ow, w->d, w->md, &ls, 1, NULL, &gen);
 		fclose(ls.out);
-		if (w->rc) return NULL;
+		if (w->rc) break;
 		w->ts[b] = ls.ts_bs;
 	}
+	mc_model_free(kept[0]);
+	mc_model_free(kept[1]);
 	return NULL;
 }
 
@@ -687,6 +700,8 @@ int main(int argc, const char **argv)
 		/* (Rand-EM draws a data-dependent number of values per initialisation: replicate b's place in the stream has no closed form) */
 		const int by_replicate = on_device && shardable(&o) && o.n_bootstrap >= n_workers(&o) && o.em.initialization_procedure != MC_RAND_EM;
 		if (by_replicate && (rc = run_bootstrap_sharded(&o, &d, &md, &st, &ntime))) goto END;
+		mc_model *kept[2] = { NULL, NULL };
+		if (on_device && !shardable(&o)) st.sim_models = kept;
 		for (int b = 0; !by_replicate && b < o.n_bootstrap; b++) {
 			printf("Bootstrap dataset %d (of %d):", b + 1, o.n_bootstrap);
 			if (on_device) {
@@ -701,11 +716,14 @@ int main(int argc, const char **argv)
 				md.geno = d.geno = orig;
 				md.init_geno = NULL;
 			}
-			if (rc) { free(sim); goto END; }
+			if (rc) { free(sim); mc_model_free(kept[0]); mc_model_free(kept[1]); goto END; }
 			if (st.ts_bs >= st.ts_obs) ntime++;
 			printf(" test statistics bs=%f obs=%f (%f)\n", st.ts_bs, st.ts_obs, (double)ntime / (b + 1));
 		}
 		free(sim);
+		st.sim_models = NULL;
+		mc_model_free(kept[0]);
+		mc_model_free(kept[1]);
 		/* the reference divides two ints here (multiclust.c:703); kept */
 		printf("p-value to reject H0: K=%d is %f\n", st.null_K, (double)(ntime / o.n_bootstrap));
 	}
