@@ -40,7 +40,7 @@ $(BIN)/multiclust: multiclust_amd/host/mc_main.c $(LIB)/libmulticlust_host.so
 	@mkdir -p $(BIN)
 	$(CC) $(CFLAGS) -Imulticlust_amd/host -o $@ $< -L$(LIB) -lmulticlust_host -lmulticlust_hip -Wl,-rpath,'$$ORIGIN/../lib' -lm -lpthread
 
-oracle:
+oracle: $(LIB)/libmulticlust_host.so
 	$(MAKE) -C oracle all
 
 clean:
