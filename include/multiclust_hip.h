@@ -71,10 +71,20 @@ int mchip_get_genotypes(mchip_context *ctx, uint8_t *geno);
  * inverse-CDF walk over q[i][.] (or q[.] when eta_constrained), then the allele by the walk over p[k][l][.], with
  * r = rand() / RAND_MAX and the reference's left-to-right partial sums.  q is [I][K] (or [K]), p is [K][T] (the H0
  * MLEs, multiclust.c:562-581).  Consumes 2*I*L*ploidy draws; every copy is simulated, as in the reference's default
- * build.  Like mchip_set_genotypes it drops any model: call mchip_set_model next.
+ * build.  Like mchip_set_genotypes it drops any model: call mchip_set_model next.  When the context already holds a data set
+ * of the same shape and allele lists (the previous replicate), every device buffer is re-used, the observed haplotypes
+ * installed by mchip_set_init_genotypes stay in force (the reference's dat->IL stays in place across replicates,
+ * bootstrap.c:35-41), and an mchip_set_model with unchanged arguments re-uses the model's buffers too.
  */
 int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int32_t *uniquealleles,
 			     const uint32_t *window, int K, int eta_constrained, const double *q, const double *p);
+/*
+ * The data set `src` holds, copied into `ctx` on the device (both contexts on one device).  run_bootstrap fits the null and the
+ * alternative model to the SAME simulated data set (multiclust.c:675-708: one parametric_bootstrap(), then estimate_model()
+ * over both K): the second model's context takes the first one's instead of generating it again.  Like
+ * mchip_simulate_genotypes it keeps the init genotypes in force when the shape is unchanged and drops any model.
+ */
+int mchip_copy_genotypes(mchip_context *ctx, const mchip_context *src);
 /*
  * The genotype the hard-partition M step reads, when it is not the data set itself.  While bootstrapping, the
  * reference's random_allele_partition still reads the observed haplotypes dat->IL (rnd_init.c:471;

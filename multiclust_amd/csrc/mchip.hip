@@ -50,6 +50,7 @@ struct mchip_context {
 	uint8_t *d_gtA, *d_gtS, *d_gtC;
 	int count_bits, has_missing;
 	unsigned long long nnz_cells, n_copies;	/* cells with n_ic > 0, non-missing allele copies (mchip_data_counts) */
+	int counts_valid;
 	size_t geno_bytes_A, geno_bytes_S;
 	uint8_t *d_asA, *d_asS;		/* hard-partition scratch, allocated on first use */
 	uint8_t *d_initA, *d_initS;	/* genotype the hard-partition M step reads when it is not the data set itself (bootstrap) */
@@ -122,40 +123,67 @@ template <typename Tp> struct scoped_dev {
 /* ------------------------------------------------------------------ K-independent kernels */
 
 /* raw [I][L][pl] bytes -> gtA [ceil(I/8)][L][8][pl] and gtS [ceil(L/8)][I][8][pl]; pads with 0xFF;
- * validates allele indices when ua != nullptr (limit = ua[l]) or against `limit` otherwise */
-__global__ void k_relayout(const uint8_t *__restrict__ raw, int I, int L, int pl, const int32_t *__restrict__ ua,
-			   int limit, uint8_t *gtA, uint8_t *gtS, size_t nA, size_t nS, int *bad)
+ * validates allele indices when ua != nullptr (limit = ua[l]) or against `limit` otherwise.
+ * A workgroup moves one tile of RT_I individuals x RT_L loci through LDS: the rows of the tile are read once, contiguously
+ * (RT_L * pl bytes per row), and both layouts are written in runs of whole 8 * pl-byte groups that are contiguous in memory
+ * (gtA: consecutive loci of one block of 8 individuals; gtS: consecutive individuals of one block of 8 loci).  The first
+ * version read raw[] once per OUTPUT byte in output order -- 8 rows per group, a few bytes of every 64-byte line at a time:
+ * 28.5 GB of HBM traffic for a 2 GB genotype (profiles/r01_v5_c3_traffic.json); it is paid per initialisation (the
+ * partition takes the same route) and per bootstrap replicate. */
+constexpr int RT_I = 64;	/* individuals per tile; loci per tile: 64 up to ploidy 8, fewer above (32 KiB of LDS) */
+
+__global__ __launch_bounds__(256) void k_relayout(const uint8_t *__restrict__ raw, int I, int L, int pl, const int32_t *__restrict__ ua,
+			   int limit, uint8_t *gtA, uint8_t *gtS, int n_ltiles, int RT_L, int *bad)
 {
-	/* grid-stride: a launch cannot have 2^32 work-items, and a config-3-sized data set already has 2e9 bytes per layout */
-	const size_t stride = (size_t)gridDim.x * blockDim.x;
-	const size_t nmax = nA > nS ? nA : nS;
-	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nmax; idx += stride) {
-		if (idx < nA) {
-			size_t r = idx;
-			const int a = (int)(r % pl); r /= pl;
-			const int j = (int)(r % 8); r /= 8;
-			const int l = (int)(r % L);
-			const size_t ib = r / L;
-			const size_t i = ib * 8 + j;
-			uint8_t v = 0xFF;
-			if (i < (size_t)I) {
-				v = raw[(i * L + l) * pl + a];
-				const int lim = ua ? ua[l] : limit;
-				if (v != 0xFF && (int)v >= lim) atomicOr(bad, 1);
-				if (v == 0xFF) atomicOr(bad, 2);	/* bit 1: the data set has missing copies */
-			}
-			gtA[idx] = v;
+	extern __shared__ uint8_t tile[];	/* [RT_I][RT_L * pl] */
+	const int rowb = RT_L * pl;		/* bytes per tile row */
+	const int l0 = (blockIdx.x % n_ltiles) * RT_L, i0 = (blockIdx.x / n_ltiles) * RT_I;
+	int flags = 0;
+	for (int x = threadIdx.x; x < RT_I * rowb; x += 256) {
+		const int r = x / rowb, cb = x % rowb;
+		const int i = i0 + r, l = l0 + cb / pl;
+		uint8_t v = 0xFF;
+		if (i < I && l < L) {
+			v = raw[((size_t)i * L + l0) * pl + cb];
+			const int lim = ua ? ua[l] : limit;
+			if (v != 0xFF && (int)v >= lim) flags |= 1;
+			if (v == 0xFF) flags |= 2;	/* bit 1: the data set has missing copies */
 		}
-		if (idx < nS) {
-			size_t r = idx;
-			const int a = (int)(r % pl); r /= pl;
-			const int j = (int)(r % 8); r /= 8;
-			const size_t i = r % I;
-			const size_t lb = r / I;
-			const size_t l = lb * 8 + j;
-			gtS[idx] = (l < (size_t)L) ? raw[(i * L + l) * pl + a] : (uint8_t)0xFF;
-		}
+		tile[x] = v;
 	}
+	if (flags) atomicOr(bad, flags);
+	__syncthreads();
+	const int grp = 8 * pl;			/* bytes per group of 8 entries */
+	/* gtA: block ib of 8 individuals, loci l0 .. l0+RT_L-1: RT_L groups, contiguous */
+	for (int x = threadIdx.x; x < (RT_I / 8) * RT_L * grp; x += 256) {
+		const int a = x % pl, j = (x / pl) % 8, ll = (x / grp) % RT_L, ibl = x / (grp * RT_L);
+		const int l = l0 + ll;
+		const size_t ib = (size_t)(i0 / 8) + ibl;
+		if (l < L && ib * 8 < (size_t)I)
+			gtA[((ib * L + l) * 8 + j) * (size_t)pl + a] = tile[(ibl * 8 + j) * rowb + ll * pl + a];
+	}
+	/* gtS: block lb of 8 loci, individuals i0 .. i0+RT_I-1: RT_I groups, contiguous */
+	for (int x = threadIdx.x; x < (RT_L / 8) * RT_I * grp; x += 256) {
+		const int a = x % pl, j = (x / pl) % 8, r = (x / grp) % RT_I, lbl = x / (grp * RT_I);
+		const int i = i0 + r;
+		const size_t lb = (size_t)(l0 / 8) + lbl;
+		if (i < I && lb * 8 < (size_t)L)
+			gtS[((lb * I + i) * 8 + j) * (size_t)pl + a] = tile[r * rowb + (lbl * 8 + j) * pl + a];
+	}
+}
+
+/* launch: one workgroup per tile; LDS = RT_I * RT_L * pl <= 32 KiB */
+static int launch_relayout(hipStream_t stream, const uint8_t *raw, int I, int L, int pl, const int32_t *ua, int limit,
+			   uint8_t *gtA, uint8_t *gtS, int *bad)
+{
+	int RT_L = 64;
+	while (RT_L > 8 && RT_I * RT_L * pl > 32 * 1024) RT_L -= 8;
+	const int n_ltiles = (L + RT_L - 1) / RT_L, n_itiles = (I + RT_I - 1) / RT_I;
+	const size_t blocks = (size_t)n_ltiles * n_itiles;
+	if (blocks >= ((size_t)1 << 31) || (size_t)RT_I * RT_L * pl > 64 * 1024) return -1;
+	hipLaunchKernelGGL(k_relayout, dim3((unsigned)blocks), dim3(256), (size_t)RT_I * RT_L * pl, stream, raw, I, L, pl, ua, limit, gtA, gtS,
+			   n_ltiles, RT_L, bad);
+	return 0;
 }
 
 /* ------------------------------------------------------------------ libc-compatible rand() on the device
@@ -940,9 +968,8 @@ static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
 	const int I = ctx->I, L = ctx->L, ploidy = ctx->ploidy, T = ctx->T;
 	int *d_bad = bad_flag(ctx);
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
-	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
-	hipLaunchKernelGGL(k_relayout, dim3(nblk_capped(nmax)), dim3(256), 0, ctx->stream, d_raw, I, L, ploidy, ctx->d_ua, 0,
-			   ctx->d_gtA, ctx->d_gtS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
+	if (launch_relayout(ctx->stream, d_raw, I, L, ploidy, ctx->d_ua, 0, ctx->d_gtA, ctx->d_gtS, d_bad))
+		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "data set too large for the layout kernel%s", nullptr);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -953,18 +980,7 @@ static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
 	}
 	if (ctx->has_missing != ((bad & 2) ? 1 : 0)) drop_graphs(ctx);	/* parked model buffers: the kernel variant changes */
 	ctx->has_missing = (bad & 2) ? 1 : 0;
-	{	/* non-empty cells and allele copies of the data set (integer sums: order does not matter) */
-		unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(ctx->d_scalars + 60), h_cnt[2] = {0, 0};
-		HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
-		const size_t n = (size_t)((I + 7) / 8) * T;
-		hipLaunchKernelGGL(k_count_cells, dim3(nblk_capped(n) > 65536u ? 65536u : nblk_capped(n)), dim3(256), 0, ctx->stream, ctx->d_gtA, I, L,
-				   ploidy, T, ctx->d_col_locus, ctx->d_col_allele, d_cnt);
-		HIPCHK(hipGetLastError());
-		HIPCHK(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, ctx->stream));
-		HIPCHK(hipStreamSynchronize(ctx->stream));
-		ctx->nnz_cells = h_cnt[0];
-		ctx->n_copies = h_cnt[1];
-	}
+	ctx->counts_valid = 0;	/* counted when asked for (mchip_data_counts): a bootstrap replicate never asks */
 	/* packed per-column allele counts for the column pass */
 	ctx->count_bits = ploidy <= 3 ? 2 : (ploidy <= 15 ? 4 : 0);
 	if (getenv("MCHIP_NO_COUNTS")) ctx->count_bits = 0;
@@ -996,6 +1012,32 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	return install_raw(ctx, ctx->d_draw);
 }
 
+int mchip_copy_genotypes(mchip_context *ctx, const mchip_context *src)
+{
+	if (!ctx || !src || ctx == src) return MCHIP_ERR_INVALID;
+	if (!src->T) return fail(ctx, MCHIP_ERR_STATE, "copy_genotypes: the source holds no data set%s", nullptr);
+	if (src->device != ctx->device) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "copy_genotypes: contexts on different devices%s", nullptr);
+	int rc = set_shape(ctx, src->I, src->L, src->ploidy, src->h_ua.data(), 1);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(src->stream));
+	HIPCHK(hipMemcpyAsync(ctx->d_gtA, src->d_gtA, ctx->geno_bytes_A, hipMemcpyDeviceToDevice, ctx->stream));
+	HIPCHK(hipMemcpyAsync(ctx->d_gtS, src->d_gtS, ctx->geno_bytes_S, hipMemcpyDeviceToDevice, ctx->stream));
+	if (src->count_bits) {
+		const int G = 128 / src->count_bits;
+		const size_t bytes = (size_t)((ctx->I + G - 1) / G) * ctx->T * 16;
+		if (!ctx->d_gtC) HIPCHK(hipMalloc((void **)&ctx->d_gtC, bytes));
+		HIPCHK(hipMemcpyAsync(ctx->d_gtC, src->d_gtC, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+	}
+	if (ctx->has_missing != src->has_missing) drop_graphs(ctx);
+	ctx->has_missing = src->has_missing;
+	ctx->count_bits = src->count_bits;
+	ctx->counts_valid = src->counts_valid;
+	ctx->nnz_cells = src->nnz_cells;
+	ctx->n_copies = src->n_copies;
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+
 int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
 {
 	if (!ctx) return MCHIP_ERR_INVALID;
@@ -1017,9 +1059,8 @@ int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
 	if (!ctx->d_initS) HIPCHK(hipMalloc((void **)&ctx->d_initS, ctx->geno_bytes_S));
 	HIPCHK(hipMemcpyAsync(d_obs, geno, n, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
-	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
-	hipLaunchKernelGGL(k_relayout, dim3(nblk_capped(nmax)), dim3(256), 0, ctx->stream, d_obs, ctx->I, ctx->L, ctx->ploidy, ctx->d_ua, 0,
-			   ctx->d_initA, ctx->d_initS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
+	if (launch_relayout(ctx->stream, d_obs, ctx->I, ctx->L, ctx->ploidy, ctx->d_ua, 0, ctx->d_initA, ctx->d_initS, d_bad))
+		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "data set too large for the layout kernel%s", nullptr);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1037,6 +1078,20 @@ int mchip_data_counts(mchip_context *ctx, uint64_t *nonempty_cells, uint64_t *al
 {
 	if (!ctx) return MCHIP_ERR_INVALID;
 	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "no genotypes set%s", nullptr);
+	if (!ctx->counts_valid) {	/* integer sums: order does not matter */
+		HIPCHK(hipSetDevice(ctx->device));
+		unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(ctx->d_scalars + 60), h_cnt[2] = {0, 0};
+		HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
+		const size_t n = (size_t)((ctx->I + 7) / 8) * ctx->T;
+		hipLaunchKernelGGL(k_count_cells, dim3(nblk_capped(n) > 65536u ? 65536u : nblk_capped(n)), dim3(256), 0, ctx->stream, ctx->d_gtA,
+				   ctx->I, ctx->L, ctx->ploidy, ctx->T, ctx->d_col_locus, ctx->d_col_allele, d_cnt);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, ctx->stream));
+		HIPCHK(hipStreamSynchronize(ctx->stream));
+		ctx->nnz_cells = h_cnt[0];
+		ctx->n_copies = h_cnt[1];
+		ctx->counts_valid = 1;
+	}
 	if (nonempty_cells) *nonempty_cells = ctx->nnz_cells;
 	if (allele_copies) *allele_copies = ctx->n_copies;
 	return MCHIP_OK;
@@ -1472,9 +1527,8 @@ static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to, int
 	if (!ctx->d_asS) HIPCHK(hipMalloc((void **)&ctx->d_asS, ctx->geno_bytes_S));
 	int *d_bad = bad_flag(ctx);
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
-	const size_t nmax = ctx->geno_bytes_A > ctx->geno_bytes_S ? ctx->geno_bytes_A : ctx->geno_bytes_S;
-	hipLaunchKernelGGL(k_relayout, dim3(nblk_capped(nmax)), dim3(256), 0, ctx->stream, d_raw, ctx->I, ctx->L, ctx->ploidy,
-			   (const int32_t *)nullptr, ctx->K, ctx->d_asA, ctx->d_asS, ctx->geno_bytes_A, ctx->geno_bytes_S, d_bad);
+	if (launch_relayout(ctx->stream, d_raw, ctx->I, ctx->L, ctx->ploidy, nullptr, ctx->K, ctx->d_asA, ctx->d_asS, d_bad))
+		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "data set too large for the layout kernel%s", nullptr);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

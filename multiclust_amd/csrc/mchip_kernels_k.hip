@@ -985,11 +985,13 @@ void launch_mix_column(const mchip_pass_args &a, hipStream_t s)
 void launch_part_p(const mchip_pass_args &a, hipStream_t s)
 {
 	if (a.ploidy == 2) hipLaunchKernelGGL((k_partition_columns<2>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
+	else if (a.ploidy == 4) hipLaunchKernelGGL((k_partition_columns<4>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
 	else hipLaunchKernelGGL((k_partition_columns<0>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
 }
 void launch_part_q(const mchip_pass_args &a, hipStream_t s)
 {
 	if (a.ploidy == 2) hipLaunchKernelGGL((k_partition_individuals<2>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
+	else if (a.ploidy == 4) hipLaunchKernelGGL((k_partition_individuals<4>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
 	else hipLaunchKernelGGL((k_partition_individuals<0>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
 }
 void launch_finalize_q(int I, int, int n_lchunks, const double *Spart, const double *Qfrom, int qstride_from,

@@ -64,6 +64,7 @@ def load():
         "mchip_mstep_from_rand_partition": ([vp, vp, i32], i32),
         "mchip_get_genotypes": ([vp, vp], i32),
         "mchip_data_counts": ([vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], i32),
+        "mchip_copy_genotypes": ([vp, vp], i32),
         "mchip_simulate_genotypes": ([vp, i32, i32, i32, vp, vp, i32, i32, vp, vp], i32),
         "mchip_set_init_genotypes": ([vp, vp], i32),
         "mchip_get_expected_counts": ([vp, vp], i32),
@@ -95,7 +96,7 @@ ABI_SYMBOLS = [
     "mchip_synchronize", "mchip_set_genotypes", "mchip_set_model", "mchip_set_p", "mchip_get_p", "mchip_set_q",
     "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_em_run", "mchip_accel_run", "mchip_last_loglik", "mchip_e_step",
     "mchip_loglik", "mchip_loglik_prefetch", "mchip_mstep_from_partition", "mchip_mstep_from_rand_partition",
-    "mchip_get_genotypes", "mchip_data_counts", "mchip_simulate_genotypes", "mchip_set_init_genotypes",
+    "mchip_get_genotypes", "mchip_data_counts", "mchip_copy_genotypes", "mchip_simulate_genotypes", "mchip_set_init_genotypes",
     "mchip_get_expected_counts", "mchip_init_from_allele_centers", "mchip_copy_slot", "mchip_secant", "mchip_step_dots",
     "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
     "mchip_profile_end", "mchip_device_info", "mchip_comm_create", "mchip_comm_all_reduce", "mchip_comm_destroy",
@@ -142,6 +143,11 @@ class Context:
         a, b = C.c_uint64(), C.c_uint64()
         self._chk(self.lib.mchip_data_counts(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def copy_genotypes(self, src):
+        """take the data set another context (same device) holds"""
+        self._chk(self.lib.mchip_copy_genotypes(self.h, src.h))
+        self.I, self.L, self.ploidy, self.T = src.I, src.L, src.ploidy, src.T
 
     def get_genotypes(self):
         g = np.empty((self.I, self.L, self.ploidy), dtype=np.uint8)

@@ -113,7 +113,8 @@ void mc_reset_model_state(mc_model *mod)
 	mod->seconds_run = 0;
 }
 
-static int model_create(mc_model **out, const mc_options *opt, const mc_data *dat, int K, int device, const mc_simulation *sim)
+static int model_create(mc_model **out, const mc_options *opt, const mc_data *dat, int K, int device, const mc_simulation *sim,
+			const mc_model *like)
 {
 	mc_model *mod = calloc(1, sizeof *mod);
 	int rc;
@@ -127,15 +128,17 @@ static int model_create(mc_model **out, const mc_options *opt, const mc_data *da
 		return rc;
 	}
 	mod->owns_dev = 1;
-	if (sim)
+	if (like)
+		rc = mchip_copy_genotypes(mod->dev, like->dev);
+	else if (sim)
 		rc = mchip_simulate_genotypes(mod->dev, dat->I, dat->L, dat->ploidy, dat->uniquealleles, sim->window, sim->K,
 					      opt->eta_constrained, sim->q, sim->p);
 	else
 		rc = mchip_set_genotypes(mod->dev, dat->I, dat->L, dat->ploidy, dat->uniquealleles, dat->geno);
 	/* fits to a bootstrap data set initialise from the observed haplotypes (rnd_init.c:471): dat->geno when the data set
 	 * was generated on the device, dat->init_geno when the caller uploaded a replicate as dat->geno */
-	if (!rc && opt->admixture && (sim || dat->init_geno))
-		rc = mchip_set_init_genotypes(mod->dev, sim ? dat->geno : dat->init_geno);
+	if (!rc && opt->admixture && (sim || like || dat->init_geno))
+		rc = mchip_set_init_genotypes(mod->dev, (sim || like) ? dat->geno : dat->init_geno);
 	if (rc || (rc = mchip_set_model(mod->dev, K, opt->admixture, opt->eta_constrained, opt->do_projection,
 					opt->eta_lower_bound, opt->p_lower_bound, opt->accel_scheme ? opt->q : 0))) {
 		fprintf(stderr, "ERROR [mc_em.c::mc_model_create]: %s\n", mchip_last_error(mod->dev));
@@ -150,13 +153,28 @@ static int model_create(mc_model **out, const mc_options *opt, const mc_data *da
 
 int mc_model_create(mc_model **out, const mc_options *opt, const mc_data *dat, int K, int device)
 {
-	return model_create(out, opt, dat, K, device, NULL);
+	return model_create(out, opt, dat, K, device, NULL, NULL);
 }
 
 int mc_model_create_simulated(mc_model **out, const mc_options *opt, const mc_data *dat, int K, int device, const mc_simulation *sim)
 {
 	if (!sim || !opt->admixture) return MCHIP_ERR_INVALID;	/* the mixture model's replicate is drawn on the host */
-	return model_create(out, opt, dat, K, device, sim);
+	return model_create(out, opt, dat, K, device, sim, NULL);
+}
+
+/* The second model of a bootstrap replicate: fitted to the data set `like` already holds (generated once per replicate,
+ * as parametric_bootstrap() is called once, multiclust.c:690); *out == NULL creates the model, otherwise it is re-used. */
+int mc_model_share_simulated(mc_model **out, const mc_options *opt, const mc_data *dat, int K, int device, const mc_model *like)
+{
+	int rc;
+	if (!like || !opt->admixture) return MCHIP_ERR_INVALID;
+	if (!*out) return model_create(out, opt, dat, K, device, NULL, like);
+	rc = mchip_copy_genotypes((*out)->dev, like->dev);
+	if (!rc) rc = mchip_set_model((*out)->dev, (*out)->K, opt->admixture, opt->eta_constrained, opt->do_projection,
+				      opt->eta_lower_bound, opt->p_lower_bound, opt->accel_scheme ? opt->q : 0);
+	if (rc) fprintf(stderr, "ERROR [mc_em.c::mc_model_share_simulated]: %s\n", mchip_last_error((*out)->dev));
+	mc_reset_model_state(*out);
+	return rc;
 }
 
 /* The next bootstrap replicate into a model that already holds one of the same observed data set (same K, same options):

@@ -159,7 +159,10 @@ int mc_fit_replicate(const mc_options *opt, const mc_data *dat, int device, cons
 		mc_model *mod = NULL;
 		const int timing = getenv("MC_TIMING") != NULL;	/* diagnostics: where a replicate spends its time */
 		double t0 = timing ? now_ms() : 0, t1, t2, t3;
-		if (models && models[h]) {
+		if (h && models && models[0]) {	/* the alternative model takes the data set the null model was just fitted to */
+			if ((rc = mc_model_share_simulated(&models[1], opt, dat, K, device, models[0]))) break;
+			mod = models[1];
+		} else if (models && models[h]) {
 			mod = models[h];
 			if ((rc = mc_model_resimulate(mod, opt, dat, &gen))) break;
 		} else {

@@ -108,6 +108,7 @@ void mc_simulation_begin(mc_simulation *sim, const mc_options *opt, const mc_dat
 int mc_model_create_simulated(mc_model **mod, const mc_options *opt, const mc_data *dat, int K, int device,
 			      const mc_simulation *sim);
 int mc_model_resimulate(mc_model *mod, const mc_options *opt, const mc_data *dat, const mc_simulation *sim);
+int mc_model_share_simulated(mc_model **mod, const mc_options *opt, const mc_data *dat, int K, int device, const mc_model *like);
 int mc_model_get_genotypes(mc_model *mod, uint8_t *geno);
 const char *mc_model_error(const mc_model *mod);
 int mc_model_set_p(mc_model *mod, int slot, const double *p);

@@ -498,7 +498,11 @@ static int estimate_model(const mc_cli_options *o, const mc_cli_data *d, const m
 		} else {
 			mc_model *mod = NULL;
 			mc_model **slot = (sim && st->sim_models) ? &st->sim_models[K == st->alt_K ? 1 : 0] : NULL;
-			if (slot && *slot && (*slot)->K == K) {
+			if (slot && K == st->alt_K && st->alt_K != st->null_K && st->sim_models[0] && (!*slot || (*slot)->K == K)) {
+				/* the alternative model takes the data set the null model of this replicate was just fitted to */
+				if ((rc = mc_model_share_simulated(slot, &o->em, md, K, o->device, st->sim_models[0]))) return rc;
+				mod = *slot;
+			} else if (slot && *slot && (*slot)->K == K) {
 				mod = *slot;
 				if ((rc = mc_model_resimulate(mod, &o->em, md, sim))) return rc;
 			} else {
