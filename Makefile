@@ -7,7 +7,7 @@ CFLAGS   = -std=gnu11 -O2 -fPIC -Wall -Wextra -Iinclude
 
 OBJ  = build/obj
 LIB  = multiclust_amd/lib
-KS   = 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 19 20 21 22 23 24 25 26 27 28 29 30 31 32
+KS   = $(shell seq 1 64)
 KOBJ = $(foreach k,$(KS),$(OBJ)/mchip_k$(k).o)
 
 BIN  = multiclust_amd/bin

@@ -26,7 +26,8 @@ extern "C" {
 
 #define MCHIP_ABI_VERSION 1
 #define MCHIP_MISSING 0xFF	/* genotype byte for a missing allele copy (reference MISSING = -9, multiclust.h:140) */
-#define MCHIP_MAX_K 32		/* clusters supported by the K-specialised kernels (cost ~ 2K+6 per cell up to K ~ 20) */
+#define MCHIP_MAX_K 64		/* clusters supported by the K-specialised kernels (cost ~ 2K+6 per cell up to K ~ 20; above
+				 * that the 2K-4K doubles a lane holds cost occupancy, above 32 they spill) */
 #define MCHIP_MAX_SECANTS 3	/* options::q <= 3 without LAPACK (multiclust.c:847-851) */
 
 enum mchip_status {

@@ -16,19 +16,26 @@ DECL_KT(1) DECL_KT(2) DECL_KT(3) DECL_KT(4) DECL_KT(5) DECL_KT(6) DECL_KT(7) DEC
 DECL_KT(9) DECL_KT(10) DECL_KT(11) DECL_KT(12) DECL_KT(13) DECL_KT(14) DECL_KT(15) DECL_KT(16)
 DECL_KT(17) DECL_KT(18) DECL_KT(19) DECL_KT(20) DECL_KT(21) DECL_KT(22) DECL_KT(23) DECL_KT(24)
 DECL_KT(25) DECL_KT(26) DECL_KT(27) DECL_KT(28) DECL_KT(29) DECL_KT(30) DECL_KT(31) DECL_KT(32)
+DECL_KT(33) DECL_KT(34) DECL_KT(35) DECL_KT(36) DECL_KT(37) DECL_KT(38) DECL_KT(39) DECL_KT(40)
+DECL_KT(41) DECL_KT(42) DECL_KT(43) DECL_KT(44) DECL_KT(45) DECL_KT(46) DECL_KT(47) DECL_KT(48)
+DECL_KT(49) DECL_KT(50) DECL_KT(51) DECL_KT(52) DECL_KT(53) DECL_KT(54) DECL_KT(55) DECL_KT(56)
+DECL_KT(57) DECL_KT(58) DECL_KT(59) DECL_KT(60) DECL_KT(61) DECL_KT(62) DECL_KT(63) DECL_KT(64)
 
 const mchip_ktable *mchip_get_ktable(int K)
 {
 	typedef const mchip_ktable *(*getter)();
 	static const getter tabs[MCHIP_MAX_K + 1] = {
-		nullptr, mchip_ktable_get_1, mchip_ktable_get_2, mchip_ktable_get_3, mchip_ktable_get_4, mchip_ktable_get_5,
-		mchip_ktable_get_6, mchip_ktable_get_7, mchip_ktable_get_8, mchip_ktable_get_9, mchip_ktable_get_10,
-		mchip_ktable_get_11, mchip_ktable_get_12, mchip_ktable_get_13, mchip_ktable_get_14, mchip_ktable_get_15,
-		mchip_ktable_get_16, mchip_ktable_get_17, mchip_ktable_get_18, mchip_ktable_get_19, mchip_ktable_get_20,
-		mchip_ktable_get_21, mchip_ktable_get_22, mchip_ktable_get_23, mchip_ktable_get_24, mchip_ktable_get_25,
-		mchip_ktable_get_26, mchip_ktable_get_27, mchip_ktable_get_28, mchip_ktable_get_29, mchip_ktable_get_30,
-		mchip_ktable_get_31, mchip_ktable_get_32,
+		nullptr,
+		mchip_ktable_get_1, mchip_ktable_get_2, mchip_ktable_get_3, mchip_ktable_get_4, mchip_ktable_get_5, mchip_ktable_get_6, mchip_ktable_get_7, mchip_ktable_get_8,
+		mchip_ktable_get_9, mchip_ktable_get_10, mchip_ktable_get_11, mchip_ktable_get_12, mchip_ktable_get_13, mchip_ktable_get_14, mchip_ktable_get_15, mchip_ktable_get_16,
+		mchip_ktable_get_17, mchip_ktable_get_18, mchip_ktable_get_19, mchip_ktable_get_20, mchip_ktable_get_21, mchip_ktable_get_22, mchip_ktable_get_23, mchip_ktable_get_24,
+		mchip_ktable_get_25, mchip_ktable_get_26, mchip_ktable_get_27, mchip_ktable_get_28, mchip_ktable_get_29, mchip_ktable_get_30, mchip_ktable_get_31, mchip_ktable_get_32,
+		mchip_ktable_get_33, mchip_ktable_get_34, mchip_ktable_get_35, mchip_ktable_get_36, mchip_ktable_get_37, mchip_ktable_get_38, mchip_ktable_get_39, mchip_ktable_get_40,
+		mchip_ktable_get_41, mchip_ktable_get_42, mchip_ktable_get_43, mchip_ktable_get_44, mchip_ktable_get_45, mchip_ktable_get_46, mchip_ktable_get_47, mchip_ktable_get_48,
+		mchip_ktable_get_49, mchip_ktable_get_50, mchip_ktable_get_51, mchip_ktable_get_52, mchip_ktable_get_53, mchip_ktable_get_54, mchip_ktable_get_55, mchip_ktable_get_56,
+		mchip_ktable_get_57, mchip_ktable_get_58, mchip_ktable_get_59, mchip_ktable_get_60, mchip_ktable_get_61, mchip_ktable_get_62, mchip_ktable_get_63, mchip_ktable_get_64,
 	};
+	static_assert(MCHIP_MAX_K == 64, "one kernel translation unit per K (Makefile: KS)");
 	return (K >= 1 && K <= MCHIP_MAX_K) ? tabs[K]() : nullptr;
 }
 
@@ -135,40 +142,63 @@ constexpr int RT_I = 64;	/* individuals per tile; loci per tile: 64 up to ploidy
 __global__ __launch_bounds__(256) void k_relayout(const uint8_t *__restrict__ raw, int I, int L, int pl, const int32_t *__restrict__ ua,
 			   int limit, uint8_t *gtA, uint8_t *gtS, int n_ltiles, int RT_L, int *bad)
 {
-	extern __shared__ uint8_t tile[];	/* [RT_I][RT_L * pl] */
-	const int rowb = RT_L * pl;		/* bytes per tile row */
+	extern __shared__ __attribute__((aligned(16))) uint8_t tile[];	/* [RT_I][RT_L * pl] */
+	const int rowb = RT_L * pl;		/* bytes per tile row: a multiple of 8 */
 	const int l0 = (blockIdx.x % n_ltiles) * RT_L, i0 = (blockIdx.x / n_ltiles) * RT_I;
 	int flags = 0;
-	for (int x = threadIdx.x; x < RT_I * rowb; x += 256) {
-		const int r = x / rowb, cb = x % rowb;
-		const int i = i0 + r, l = l0 + cb / pl;
-		uint8_t v = 0xFF;
-		if (i < I && l < L) {
-			v = raw[((size_t)i * L + l0) * pl + cb];
-			const int lim = ua ? ua[l] : limit;
-			if (v != 0xFF && (int)v >= lim) flags |= 1;
-			if (v == 0xFF) flags |= 2;	/* bit 1: the data set has missing copies */
+	const int roww = rowb / 4;		/* dwords per tile row */
+	/* rows are read four bytes at a time when every row of the tile starts on a 4-byte boundary of raw[] and lies inside it */
+	const bool words = ((((size_t)L * pl) | ((size_t)l0 * pl) | (size_t)raw) & 3) == 0 && l0 + RT_L <= L;
+	for (int x = threadIdx.x; x < RT_I * roww; x += 256) {
+		const int r = x / roww, w = x % roww;
+		const int i = i0 + r;
+		uint32_t v4 = 0xFFFFFFFFu;
+		if (i < I) {
+			const uint8_t *src = raw + ((size_t)i * L + l0) * pl + (size_t)w * 4;
+			if (words) {
+				v4 = *reinterpret_cast<const uint32_t *>(src);
+			} else {
+				v4 = 0;
+				for (int y = 0; y < 4; y++) {
+					const int l = l0 + (w * 4 + y) / pl;
+					const uint32_t v = l < L ? src[y] : 0xFFu;
+					v4 |= v << (8 * y);
+				}
+			}
+			for (int y = 0; y < 4; y++) {
+				const int l = l0 + (w * 4 + y) / pl;
+				const uint32_t v = (v4 >> (8 * y)) & 0xFFu;
+				if (l >= L) continue;
+				const int lim = ua ? ua[l] : limit;
+				if (v != 0xFFu && (int)v >= lim) flags |= 1;
+				if (v == 0xFFu) flags |= 2;	/* bit 1: the data set has missing copies */
+			}
 		}
-		tile[x] = v;
+		reinterpret_cast<uint32_t *>(tile)[x] = v4;
 	}
 	if (flags) atomicOr(bad, flags);
 	__syncthreads();
-	const int grp = 8 * pl;			/* bytes per group of 8 entries */
-	/* gtA: block ib of 8 individuals, loci l0 .. l0+RT_L-1: RT_L groups, contiguous */
-	for (int x = threadIdx.x; x < (RT_I / 8) * RT_L * grp; x += 256) {
-		const int a = x % pl, j = (x / pl) % 8, ll = (x / grp) % RT_L, ibl = x / (grp * RT_L);
+	const int grp = 8 * pl, grpw = 2 * pl;	/* bytes / dwords per group of 8 entries */
+	/* gtA: block ib of 8 individuals, loci l0 .. l0+RT_L-1: RT_L groups, contiguous; one dword (4 of the group's bytes) per thread */
+	for (int x = threadIdx.x; x < (RT_I / 8) * RT_L * grpw; x += 256) {
+		const int w = x % grpw, ll = (x / grpw) % RT_L, ibl = x / (grpw * RT_L);
 		const int l = l0 + ll;
 		const size_t ib = (size_t)(i0 / 8) + ibl;
-		if (l < L && ib * 8 < (size_t)I)
-			gtA[((ib * L + l) * 8 + j) * (size_t)pl + a] = tile[(ibl * 8 + j) * rowb + ll * pl + a];
+		if (l >= L || ib * 8 >= (size_t)I) continue;
+		uint32_t v4 = 0;
+		for (int y = 0; y < 4; y++) {
+			const int e = w * 4 + y, j = e / pl, a = e % pl;
+			v4 |= (uint32_t)tile[(ibl * 8 + j) * rowb + ll * pl + a] << (8 * y);
+		}
+		reinterpret_cast<uint32_t *>(gtA + (ib * L + l) * (size_t)grp)[w] = v4;
 	}
-	/* gtS: block lb of 8 loci, individuals i0 .. i0+RT_I-1: RT_I groups, contiguous */
-	for (int x = threadIdx.x; x < (RT_L / 8) * RT_I * grp; x += 256) {
-		const int a = x % pl, j = (x / pl) % 8, r = (x / grp) % RT_I, lbl = x / (grp * RT_I);
+	/* gtS: block lb of 8 loci, individuals i0 .. i0+RT_I-1: RT_I groups, contiguous; the group's bytes are contiguous in the tile row */
+	for (int x = threadIdx.x; x < (RT_L / 8) * RT_I * grpw; x += 256) {
+		const int w = x % grpw, r = (x / grpw) % RT_I, lbl = x / (grpw * RT_I);
 		const int i = i0 + r;
 		const size_t lb = (size_t)(l0 / 8) + lbl;
-		if (i < I && lb * 8 < (size_t)L)
-			gtS[((lb * I + i) * 8 + j) * (size_t)pl + a] = tile[r * rowb + (lbl * 8 + j) * pl + a];
+		if (i >= I || lb * 8 >= (size_t)L) continue;
+		reinterpret_cast<uint32_t *>(gtS + (lb * I + i) * (size_t)grp)[w] = reinterpret_cast<const uint32_t *>(tile + r * rowb + lbl * grp)[w];
 	}
 }
 

@@ -783,11 +783,11 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_partition_columns(mchip_pass_ar
 					}
 				continue;
 			}
-			unsigned flags = 0;
+			unsigned long long flags = 0;
 			for (int b = 0; b < pl; b++)
-				if (g.copy(j, b, pl) == m) flags |= 1u << (s.copy(j, b, pl) & 31u);
+				if (g.copy(j, b, pl) == m) flags |= 1ull << (s.copy(j, b, pl) & 63u);
 #pragma unroll
-			for (int k = 0; k < K; k++) acc[k] += (double)((flags >> k) & 1u);
+			for (int k = 0; k < K; k++) acc[k] += (double)((flags >> k) & 1ull);
 		}
 	}
 	if (valid) {
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(QBLOCK) void k_partition_individuals(mchip_pass_arg
 /* ---------------------------------------------------------------- simplex.c:109-143 on K registers */
 __device__ __forceinline__ void michelot_k(double (&x)[K], double mn)
 {
-	unsigned fixed = 0;
+	unsigned long long fixed = 0;
 	int n = K;
 	while (n) {
 		double csum = 0.0;
@@ -846,11 +846,11 @@ __device__ __forceinline__ void michelot_k(double (&x)[K], double mn)
 		bool can_terminate = true;
 #pragma unroll
 		for (int j = 0; j < K; j++)
-			if (!((fixed >> j) & 1u)) {
+			if (!((fixed >> j) & 1ull)) {
 				x[j] -= shift;
 				if (x[j] < mn) {
 					x[j] = mn;
-					fixed |= 1u << j;
+					fixed |= 1ull << j;
 					n--;
 					can_terminate = false;
 				}

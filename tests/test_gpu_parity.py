@@ -99,6 +99,7 @@ def test_first_mstep_partition_drawn_on_device(ctx, name):
     (700, 1000, 2, 8, 0),        # 1.4e6 draws: more than one block of 256 chunks (both jump tables used)
     (301, 997, 4, 3, 1234),      # ragged tail chunk, stream already advanced, K not a power of two
     (513, 640, 2, 32, 77),       # K = 32
+    (200, 300, 2, 47, 9),        # K > 32: the partition's cluster flags are 64 bits wide
     (129, 400, 3, 7, 5),         # odd ploidy
     (64, 100, 2, 1, 0),          # K = 1: rand() % 1
     (900, 900, 2, 2, 31),
@@ -172,7 +173,7 @@ def test_invalid_inputs_are_rejected(ctx):
         ctx.set_genotypes(g.ua, bad)
     ctx.set_genotypes(g.ua, g.geno)
     with pytest.raises(mc.HipError):
-        ctx.set_model(33)                   # K > MCHIP_MAX_K
+        ctx.set_model(65)                   # K > MCHIP_MAX_K
     with pytest.raises(mc.HipError):
         ctx.set_model(0)
 
@@ -200,8 +201,8 @@ def test_mixture_em_steps_vs_reference_golden(ctx, name):
     assert abs(ctx.loglik(0) - g.m["ll_after_em"]) <= 1e-8
 
 
-def test_mixture_vs_oracle_synthetic(ctx):
-    I, L, K = 300, 700, 6
+@pytest.mark.parametrize("I,L,K", [(300, 700, 6), (120, 300, 40)])
+def test_mixture_vs_oracle_synthetic(ctx, I, L, K):
     ua, geno = make_dataset(I, L, K, ploidy=2, max_alleles=5, seed=77, missing=0.01)
     lb = ob.lib.mco_lower_bound(1e-8, I, 2)
     _, p0 = random_params(I, ua, K, seed=3, lower_bound=lb)
@@ -236,7 +237,10 @@ def test_mixture_vs_oracle_synthetic(ctx):
     (100, 300, 16, 2, 4, 0.0, {}),                                  # K = 16 (largest tuned K)
     (100, 300, 1, 2, 4, 0.0, {}),                                   # K = 1
     (80, 200, 23, 2, 4, 0.01, {}),                                  # K > 16: untuned but correct
-    (64, 128, 32, 4, 5, 0.0, {}),                                   # K = MCHIP_MAX_K, tetraploid
+    (64, 128, 32, 4, 5, 0.0, {}),                                   # K = 32, tetraploid
+    (90, 160, 33, 2, 4, 0.01, {}),                                  # K > 32: the projection's fixed-entry mask is 64 bits wide
+    (70, 140, 48, 2, 3, 0.0, {"eta_constrained": 1}),
+    (66, 130, 64, 4, 4, 0.02, {}),                                  # K = MCHIP_MAX_K, tetraploid, missing data
     (120, 240, 4, 2, 3, 0.02, {"eta_constrained": 1}),              # shared eta (-c)
     (120, 240, 4, 4, 4, 0.02, {"eta_constrained": 1}),
     (513, 64, 7, 2, 2, 0.0, {}),                                    # more individuals than a 512-wide tile, few loci
