@@ -60,6 +60,11 @@ WORKLOADS = {
                desc="2000 diploid x 20000 biallelic loci, admixture K=5, plain EM (-s 0)"),
     "c1": dict(I=100, L=500, ploidy=2, maxal=2, K=3, accel=0, dseed=1,
                desc="100 diploid x 500 biallelic loci, admixture K=3, plain EM"),
+    # reduced shapes of c4 / c5 for rehearsals of the sharded paths (tests/test_gpu_bench.py: two ranks on one GPU over gloo)
+    "c4s": dict(I=600, L=4000, ploidy=2, maxal=4, K=8, accel=3, dseed=3,
+                desc="600 diploid x 4000 loci (reduced c4), admixture K=8, SQUAREM-3, random initialisations sharded over GPUs"),
+    "c5s": dict(I=400, L=3000, ploidy=4, maxal=4, K=4, accel=0, dseed=5,
+                desc="400 tetraploid x 3000 loci (reduced c5), bootstrap of K=3 vs K=4, replicates sharded over GPUs"),
     "c5fit": dict(I=5000, L=50000, ploidy=4, maxal=4, K=8, accel=0, dseed=5,
                   desc="5000 tetraploid x 50000 loci, M_l~U{2,3,4}, admixture K=8, plain EM, single fit"),
 }
@@ -409,7 +414,7 @@ def run_units(env, fit, w, T, n_units, cycles, warmup, with_roofline=True):
     steps_on_busiest = max(1, len(shard.units_for_rank(n_units, 0, env.world))) * cycles
     out = {
         "value": total_iters / dt, "ms_per_step": dt * 1e3 / steps_on_busiest, "steps": cycles,
-        "config": {"workload": "c4: %s" % w["desc"], "I": w["I"], "L": w["L"], "T": T, "ploidy": w["ploidy"], "K": w["K"],
+        "config": {"workload": "%s: %s" % ("c4" if w["I"] == 10000 else "c4s", w["desc"]), "I": w["I"], "L": w["L"], "T": T, "ploidy": w["ploidy"], "K": w["K"],
                    "accel_scheme": accel, "em_iterations_per_step": per_cycle, "units": n_units,
                    "unit_to_rank": "u mod %d" % env.world, "max_iter": fit.opt.max_iter,
                    "timed": "rand() jump-ahead + device-side initialisation + em() of every unit + the all-reduce",
@@ -487,7 +492,7 @@ def run_bootstrap(env, w, ua, geno, n_rep, budget, n_init=1):
     del keep
     return {
         "value": total_iters / dt, "ms_per_step": dt * 1e3 / max(1, len(range(0, n_rep, env.world))), "steps": n_rep,
-        "config": {"workload": "c5: %s" % w["desc"], "I": w["I"], "L": w["L"], "T": T, "ploidy": w["ploidy"], "K": [K0, K1],
+        "config": {"workload": "%s: %s" % ("c5" if w["I"] == 5000 else "c5s", w["desc"]), "I": w["I"], "L": w["L"], "T": T, "ploidy": w["ploidy"], "K": [K0, K1],
                    "accel_scheme": 0, "replicates": n_rep, "replicate_to_rank": "b mod %d" % env.world, "n_init": n_init,
                    "max_iter": budget, "step": "one bootstrap replicate",
                    "timed": "device-side generation of every replicate + initialisation + em() of both models + the all-reduce",
@@ -533,7 +538,7 @@ def main():
     w = WORKLOADS[name]
     want_cpu = env.world == 1 and env.rank == 0 and not args.no_cpu_baseline
 
-    if name == "c5":
+    if name in ("c5", "c5s"):
         ua, geno = workload_data(w, env)
         out = run_bootstrap(env, w, ua, geno, args.replicates, args.steps)
         if want_cpu:
@@ -546,7 +551,7 @@ def main():
 
     ua, geno = workload_data(w, env)
     T = int(ua.sum())
-    if name == "c4":
+    if name in ("c4", "c4s"):
         from multiclust_amd import host
         accel = w["accel"] if args.accel is None else args.accel
         fit = host.Fit(ua, geno, w["K"], device=env.local_rank, admixture=1, accel_scheme=accel, verbosity=1, abs_error=1e-300)

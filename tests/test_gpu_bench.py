@@ -69,3 +69,33 @@ def test_c5_replicates_agree_with_command_line(tmp_path):
     assert abs(cfg["ts_obs"] - cli[0][1]) <= 2e-6
     for (bs, _), got in zip(cli, cfg["ts_first"]):
         assert abs(bs - got) <= 2e-6, (bs, got)
+
+
+def run_bench(args, env_extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(env_extra)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, res.stdout                       # exactly one JSON line on stdout
+    import json
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload", ["c4s", "c5s"])
+def test_two_ranks_give_the_one_rank_results(workload):
+    """`bench.py --gpus 2` starts two ranks by itself (here both on device 0, exchanging over gloo: the rehearsal knobs) and
+    prints n_gpus = 2; units / replicates are sharded u mod 2 and every one is accounted for exactly once; per-unit results
+    are bit for bit those of the one-rank run (a unit starts where the serial rand() stream would be, whoever fits it)."""
+    args = ["--workload", workload, "--no-cpu-baseline", "--steps", "6", "--units", "7", "--replicates", "5"]
+    one = run_bench(args, {})
+    two = run_bench(args + ["--gpus", "2"], {"MC_BENCH_DEVICE": "0", "MC_BENCH_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    c1, c2 = one["config"], two["config"]
+    if workload == "c4s":
+        assert c2["units"] == 7 and len(c2["unit_logL"]) == 7 and c2["em_iterations"] == 7 * 12
+        assert c1["unit_logL"] == c2["unit_logL"] and c1["best_unit"] == c2["best_unit"] and c1["best_logL"] == c2["best_logL"]
+    else:
+        assert c2["replicates"] == 5 and c2["em_iterations"] == 5 * 2 * 7
+        assert c1["ts_first"] == c2["ts_first"] and c1["ts_obs"] == c2["ts_obs"] and c1["p_value"] == c2["p_value"]

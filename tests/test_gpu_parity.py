@@ -99,7 +99,7 @@ def test_first_mstep_partition_drawn_on_device(ctx, name):
     (700, 1000, 2, 8, 0),        # 1.4e6 draws: more than one block of 256 chunks (both jump tables used)
     (301, 997, 4, 3, 1234),      # ragged tail chunk, stream already advanced, K not a power of two
     (513, 640, 2, 32, 77),       # K = 32
-    (200, 300, 2, 47, 9),        # K > 32: the partition's cluster flags are 64 bits wide
+    (1500, 64, 2, 47, 9),        # K > 32: the partition's cluster flags are 64 bits wide (enough copies that no cluster is empty at a locus)
     (129, 400, 3, 7, 5),         # odd ploidy
     (64, 100, 2, 1, 0),          # K = 1: rand() % 1
     (900, 900, 2, 2, 31),
