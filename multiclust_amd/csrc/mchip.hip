@@ -46,7 +46,7 @@ struct mchip_context {
 	char err[512];
 	int n_cu;
 	/* data set */
-	int I, L, ploidy, T, max_M;
+	int I, L, ploidy, T, max_M, min_M;
 	std::vector<int32_t> h_ua;	/* host copy of uniquealleles: a data set of the same shape reuses every buffer */
 	int parked_K;			/* model buffers kept allocated for this K (and the signature below) while no model is set */
 	int sig_admixture, sig_constrained, sig_projection, sig_nsec;
@@ -834,6 +834,7 @@ static mchip_pass_args pass_args(mchip_context *ctx, int slot)
 	a.lchunk = ctx->lchunk; a.n_lchunks = ctx->n_lchunks; a.Spart = ctx->d_Spart;
 	a.asA = ctx->d_asA; a.asS = ctx->d_asS;
 	a.sparse = ctx->sparse; a.tile_cols = 8 * ctx->max_M;
+	a.biallelic = (ctx->min_M == 2 && ctx->max_M == 2 && !getenv("MCHIP_NO_BIAL")) ? 1 : 0;
 	return a;
 }
 
@@ -947,8 +948,9 @@ static int set_shape(mchip_context *ctx, int I, int L, int ploidy, const int32_t
 
 	std::vector<int32_t> toff(L + 9);	/* padded: kernels read 8 offsets per locus block */
 	toff[0] = 0;
-	int maxM = 0;
+	int maxM = 0, minM = 1 << 30;
 	for (int l = 0; l < L; l++) {
+		if (ua[l] < minM) minM = ua[l];
 		if (ua[l] < 0 || ua[l] > 255) return fail(ctx, MCHIP_ERR_INVALID, "uniquealleles[l] must be in [0,255]%s", nullptr);
 		if ((long long)toff[l] + ua[l] > 2000000000LL) return fail(ctx, MCHIP_ERR_INVALID, "too many allele columns%s", nullptr);
 		toff[l + 1] = toff[l] + ua[l];
@@ -964,7 +966,7 @@ static int set_shape(mchip_context *ctx, int I, int L, int ploidy, const int32_t
 			col_locus[toff[l] + m] = l;
 			col_allele[toff[l] + m] = (uint8_t)m;
 		}
-	ctx->I = I; ctx->L = L; ctx->ploidy = ploidy; ctx->T = T; ctx->max_M = maxM;
+	ctx->I = I; ctx->L = L; ctx->ploidy = ploidy; ctx->T = T; ctx->max_M = maxM; ctx->min_M = minM;
 	ctx->h_ua.assign(ua, ua + L);
 	ctx->geno_bytes_A = (size_t)((I + 7) / 8) * L * 8 * ploidy;
 	ctx->geno_bytes_S = (size_t)((L + 7) / 8) * I * 8 * ploidy;

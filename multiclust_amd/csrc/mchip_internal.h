@@ -53,6 +53,7 @@ struct mchip_pass_args {
 	/* sparse individual pass: P rows of 8 loci staged in LDS */
 	int sparse;		/* 1: sparse individual pass + N-only column pass; 0: dense pair */
 	int tile_cols;		/* LDS tile capacity in allele columns (8 * max alleles per locus) */
+	int biallelic;		/* every locus has exactly two allele columns: column of (l, m) is 2l + m */
 	/* batched runs: when non-null and *stop != 0 every kernel of the step returns at once */
 	const int *stop;
 	/* batched accelerated runs: when non-null and *skip_ind != 0 the S-side pass returns at once, because the pass that

@@ -593,6 +593,85 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 	if (threadIdx.x == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }
 
+/* ---------------------------------------------------------------- individual pass, every locus biallelic (SNP data)
+ * When every locus has exactly two allele columns (diploid data without missing-data phantom slots) column c of locus l is
+ * 2l + m and the two rows of a locus are wave-uniform: they come through the scalar cache as SGPR operands of the FMAs, no
+ * LDS tile, no per-lane gather.  Both alleles' t are computed for every individual (2K FMAs, the same count as two copies),
+ * the genotype only selects which of them enter the log-product, and the S-side sums take P_0 n_0/t_0 + P_1 n_1/t_1 with one
+ * reciprocal.  The stand-alone log-likelihood pass, LDS-bound in the general kernel, becomes FP64-bound here. */
+template <bool ACCUM, bool NOMISS>
+__global__ __launch_bounds__(QBLOCK) void k_individual_bial(mchip_pass_args a)
+{
+	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
+	if (ACCUM && a.skip_ind && *a.skip_ind) return;
+	__shared__ double red[QBLOCK];
+	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
+	const bool active = i_raw < a.I;
+	const int i = active ? i_raw : a.I - 1;
+	double q[K], acc[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+		q[k] = a.Q[(size_t)i * a.qstride + k];
+		acc[k] = 0.0;
+	}
+	const int l0 = blockIdx.y * a.lchunk;
+	const int l1 = min(a.L, l0 + a.lchunk);
+	const int lb0 = l0 >> 3, lb_end = (l1 + 7) >> 3;
+	double prod = 1.0;
+	int blk = 0, ex = 0;
+	geno_group<2> g, gn;
+	g.load(a.gtS, (size_t)lb0 * a.I + i, 2);
+	for (int lb = lb0; lb < lb_end; lb++) {
+		gn.load(a.gtS, (size_t)min(lb + 1, lb_end - 1) * a.I + i, 2);
+		const int nloc = l1 - lb * 8;
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			if (j < nloc) {		/* wave-uniform */
+				const double *__restrict__ r0 = a.P + (size_t)(lb * 8 + j) * 2 * K;	/* rows 2l, 2l+1: wave-uniform, s_load */
+				double t0 = q[0] * r0[0], t1 = q[0] * r0[K];
+#pragma unroll
+				for (int k = 1; k < K; k++) {
+					t0 = __builtin_fma(q[k], r0[k], t0);
+					t1 = __builtin_fma(q[k], r0[K + k], t1);
+				}
+				const unsigned ma = g.copy(j, 0, 2), mb = g.copy(j, 1, 2);
+				double ta, tb;
+				if (NOMISS) {		/* idle lanes duplicate individual I-1 and are dropped at the end */
+					ta = ma ? t1 : t0;
+					tb = mb ? t1 : t0;
+				} else {		/* a missing copy (0xFF) leaves the product alone */
+					ta = !active ? 1.0 : (ma == 0u ? t0 : (ma == 1u ? t1 : 1.0));
+					tb = !active ? 1.0 : (mb == 0u ? t0 : (mb == 1u ? t1 : 1.0));
+				}
+				if (ACCUM) {
+					const double rp = rcp_full(t0 * t1);
+					const double n0 = (double)((int)(ma == 0u) + (int)(mb == 0u)), n1 = (double)((int)(ma == 1u) + (int)(mb == 1u));
+					const double R0 = n0 * (rp * t1), R1 = n1 * (rp * t0);
+#pragma unroll
+					for (int k = 0; k < K; k++) {
+						acc[k] = __builtin_fma(r0[k], R0, acc[k]);
+						acc[k] = __builtin_fma(r0[K + k], R1, acc[k]);
+					}
+				}
+				prod *= ta * tb;
+			}
+		}
+		if (++blk >= a.flush_blocks) {
+			blk = 0;
+			rescale(prod, ex);
+		}
+		g = gn;
+	}
+	const double ll = (double)ex * 0.693147180559945309417 + log(prod);
+	if (ACCUM && active) {
+		double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
+#pragma unroll
+		for (int k = 0; k < K; k++) out[k] = acc[k];
+	}
+	const double tot = block_sum<QBLOCK>(active ? ll : 0.0, red);
+	if (threadIdx.x == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
 /* ---------------------------------------------------------------- mixture model (em_alg.c:763-1011)
  * E step: v_ik = log eta_k + sum_{l,m: n>0} n log p_klm.  log P is tabulated once per step ([T][K], k_logp in
  * mchip.hip); the per-individual sum is a gather-add over the alleles the individual carries (one add per
@@ -936,6 +1015,15 @@ template <bool ACCUM> void launch_sparse(const mchip_pass_args &a, hipStream_t s
 	const size_t lds = sparse_lds_bytes(a);
 	const bool nomiss = !a.has_missing;	/* idle lanes of the last block recompute individual I-1 and are dropped at the end */
 	const bool safe = a.flush_blocks < 1;
+	/* measured (profiles/r02_biallelic_variant.txt): the stand-alone log-likelihood pass gains 6-21 % from K = 6 up (it is
+	 * LDS-bound in the general kernel), the S-side pass only from K = 10 (it is FP64-bound, and the dense-over-two-alleles
+	 * form costs more instructions per locus: +8-19 % below that) */
+	constexpr bool bial_pays = ACCUM ? (K >= 10) : (K >= 6);
+	if (bial_pays && a.biallelic && a.ploidy == 2 && !safe) {
+		if (nomiss) hipLaunchKernelGGL((k_individual_bial<ACCUM, true>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
+		else hipLaunchKernelGGL((k_individual_bial<ACCUM, false>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
+		return;
+	}
 #define MCHIP_SPARSE(PLV) \
 	do { \
 		if (nomiss && !safe) hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, false, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a); \

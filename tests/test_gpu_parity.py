@@ -245,6 +245,9 @@ def test_mixture_vs_oracle_synthetic(ctx, I, L, K):
     (120, 240, 4, 4, 4, 0.02, {"eta_constrained": 1}),
     (513, 64, 7, 2, 2, 0.0, {}),                                    # more individuals than a 512-wide tile, few loci
     (9, 11, 2, 2, 2, 0.0, {}),                                      # tiny: fewer individuals / loci than any tile
+    (200, 500, 8, 2, 2, 0.0, {}),                                   # every locus biallelic: scalar-row log-likelihood pass (K >= 6)
+    (150, 401, 12, 2, 2, 0.0, {}),                                  # ... and scalar-row S-side pass (K >= 10)
+    (150, 401, 12, 2, 2, 0.02, {}),                                 # ... with missing copies (no phantom slot in this generator)
 ])
 def test_em_steps_vs_oracle_paths(ctx, I, L, K, ploidy, maxal, missing, opts):
     """Every kernel variant (dense fallback, generic ploidy, safe log-product path, shared eta, K extremes)
