@@ -431,7 +431,7 @@ def run_units(env, fit, w, T, n_units, cycles, warmup, with_roofline=True):
 
 
 # ------------------------------------------------------------------------------------------------ c5: bootstrap replicates sharded
-def run_bootstrap(env, w, ua, geno, n_rep, budget, n_init=1):
+def run_bootstrap(env, w, ua, geno, n_rep, budget, n_init=1, n_streams=1):
     """-b n_rep of K-1 vs K (multiclust.c:675-708): the observed-data fits (untimed setup, every rank computes the same bits),
     then replicate b on rank b mod N = mc_fit_replicate, timed whole."""
     from multiclust_amd import host
@@ -467,19 +467,31 @@ def run_bootstrap(env, w, ua, geno, n_rep, budget, n_init=1):
     env.barrier()
     t0 = time.perf_counter()
     rows = np.zeros((n_rep, 5))
-    models = (C.POINTER(host.McModel) * 2)()              # this rank's K-1 and K models, re-used by every replicate
-    for b in mine:
-        r = host.McReplicateResult()
-        rc = lib.mc_fit_replicate(C.byref(opt), C.byref(dat), env.local_rank, C.byref(base), b, K0, K1, n_init, K0,
-                                  mle_q.ctypes.data, mle_p.ctypes.data, C.byref(r), models)
-        if rc or r.fatal:
-            raise SystemExit("replicate %d: rc=%d fatal=%d" % (b, rc, r.fatal))
-        rows[b] = (r.ts, r.logL_H0, r.logL_HA, r.n_iter, 1.0)
-        if os.environ.get("MC_TIMING"):
-            sys.stderr.write("replicate %d done %.3f s after the start\n" % (b, time.perf_counter() - t0))
-    for mp in models:
-        if mp:
-            lib.mc_model_free(mp)
+
+    def worker(x):
+        """one of this rank's n_streams workers (host thread + its own K-1 and K models, i.e. contexts and streams, re-used
+        by every replicate it fits): a replicate's data-set generation and initialisation are latency-bound and overlap with
+        another worker's FP64-bound EM kernels -- the command line's --streams"""
+        models = (C.POINTER(host.McModel) * 2)()
+        for b in mine[x::n_streams]:
+            r = host.McReplicateResult()
+            rc = lib.mc_fit_replicate(C.byref(opt), C.byref(dat), env.local_rank, C.byref(base), b, K0, K1, n_init, K0,
+                                      mle_q.ctypes.data, mle_p.ctypes.data, C.byref(r), models)
+            if rc or r.fatal:
+                raise SystemExit("replicate %d: rc=%d fatal=%d" % (b, rc, r.fatal))
+            rows[b] = (r.ts, r.logL_H0, r.logL_HA, r.n_iter, 1.0)
+            if os.environ.get("MC_TIMING"):
+                sys.stderr.write("replicate %d done %.3f s after the start\n" % (b, time.perf_counter() - t0))
+        for mp in models:
+            if mp:
+                lib.mc_model_free(mp)
+
+    if n_streams > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(n_streams) as pool:
+            list(pool.map(worker, range(n_streams)))         # ctypes releases the GIL inside the library
+    else:
+        worker(0)
     flat = env.reduce(rows.ravel().tolist(), "SUM")         # the one exchange: disjoint rows
     rows = np.array(flat).reshape(n_rep, 5)
     env.barrier()
@@ -494,6 +506,7 @@ def run_bootstrap(env, w, ua, geno, n_rep, budget, n_init=1):
         "value": total_iters / dt, "ms_per_step": dt * 1e3 / max(1, len(range(0, n_rep, env.world))), "steps": n_rep,
         "config": {"workload": "%s: %s" % ("c5" if w["I"] == 5000 else "c5s", w["desc"]), "I": w["I"], "L": w["L"], "T": T, "ploidy": w["ploidy"], "K": [K0, K1],
                    "accel_scheme": 0, "replicates": n_rep, "replicate_to_rank": "b mod %d" % env.world, "n_init": n_init,
+                   "streams_per_gpu": n_streams,
                    "max_iter": budget, "step": "one bootstrap replicate",
                    "timed": "device-side generation of every replicate + initialisation + em() of both models + the all-reduce",
                    "time_to_finish_s": dt, "replicates_per_s": n_rep / dt, "em_iterations": total_iters,
@@ -523,6 +536,7 @@ def main():
     ap.add_argument("--accel", type=int, default=None, help="override the workload's acceleration scheme (0..6)")
     ap.add_argument("--units", type=int, default=50, help="c4: random initialisations sharded over the GPUs")
     ap.add_argument("--replicates", type=int, default=200, help="c5: bootstrap replicates sharded over the GPUs")
+    ap.add_argument("--streams", type=int, default=2, help="c5: concurrent replicates per GPU (host thread + contexts + streams each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra workloads carried on the default line (profiling "
@@ -540,7 +554,7 @@ def main():
 
     if name in ("c5", "c5s"):
         ua, geno = workload_data(w, env)
-        out = run_bootstrap(env, w, ua, geno, args.replicates, args.steps)
+        out = run_bootstrap(env, w, ua, geno, args.replicates, args.steps, n_streams=args.streams)
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(w, ua, geno, 0, args.cpu_budget, env.local_rank)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
@@ -587,7 +601,7 @@ def main():
         else:
             w5 = WORKLOADS["c5"]
             ua5, geno5 = workload_data(w5, env)
-            c5 = run_bootstrap(env, w5, ua5, geno5, args.replicates, args.steps)
+            c5 = run_bootstrap(env, w5, ua5, geno5, args.replicates, args.steps, n_streams=args.streams)
             sec["c5"] = dict(c5, unit="EM iterations/s", scaling="strong")
         out["secondary"] = sec
     else:
