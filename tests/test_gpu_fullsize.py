@@ -304,3 +304,45 @@ def test_beyond_2_pow_32_allele_copies():
         lls.append(c.loglik(0))
         c.close()
     assert abs(sum(lls) - ll_full) <= 1e-11 * abs(ll_full), (lls, ll_full)
+
+
+def test_config4_units_are_independent_of_who_fits_them():
+    """BASELINE.json configs[3] at size: units of one data set sharded u -> rank u mod N.  Unit u must be the serial program's
+    initialisation u whoever fits it and whatever that context fitted before: unit 3 (its partition starts 6e9 draws into the
+    rand() stream, past 2^32) fitted after units 0 and 1 by one context, and alone by a fresh context, give the same bits;
+    its device-drawn partition equals the host generator jumped to its first draw on the last individuals."""
+    import ctypes as C
+    from multiclust_amd import host
+    I, L, K = 10000, 100000, 8
+    ua, geno = fast_geno(I, L, 2, 4, seed=20250123)
+    opts = dict(admixture=1, accel_scheme=3, verbosity=1, abs_error=1e-300, max_iter=5)      # -T 5: 3 SQUAREM cycles
+    a = host.Fit(ua, geno, K, **opts)
+    res_a = {u: a.fit_unit(1234567, u) for u in (0, 1, 3)}
+    qa, pa = a.get_q(a.mod.pindex), a.get_p(a.mod.pindex)
+    a.close()
+    b = host.Fit(ua, geno, K, **opts)
+    r3 = b.fit_unit(1234567, 3)
+    assert (r3.logL, r3.n_iter, r3.pindex) == (res_a[3].logL, res_a[3].n_iter, res_a[3].pindex) and r3.n_iter == 6
+    assert np.array_equal(b.get_q(b.mod.pindex), qa) and np.array_equal(b.get_p(b.mod.pindex), pa)
+    assert len({res_a[u].logL for u in res_a}) == 3                                     # three different initialisations
+    # the partition unit 3 starts from: expected counts of the hard partition on the last individuals
+    rng = host.McRng()
+    b.lib.mc_srand(C.byref(rng), 1234567)
+    b.lib.mc_rng_jump(C.byref(rng), 3 * I * L * 2)
+    window = np.array([rng.r[(rng.f + t) % 31] for t in range(31)], dtype=np.int64).astype(np.uint32)
+    ctx = mc.Context(0)
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, lower_bound=1e-8)
+    ctx.mstep_from_rand_partition(window, 0)
+    cnt = ctx.expected_counts()
+    tail = 2
+    b.lib.mc_rng_jump(C.byref(rng), (I - tail) * L * 2)
+    d = np.fromiter((b.lib.mc_rand(C.byref(rng)) % K for _ in range(tail * L * 2)), dtype=np.int64, count=tail * L * 2).reshape(tail, L, 2)
+    g = geno[I - tail:]
+    exp = np.zeros((tail, K))
+    for k in range(K):
+        hit = d == k
+        exp[:, k] = hit.sum(axis=(1, 2)) - (hit[:, :, 0] & hit[:, :, 1] & (g[:, :, 0] == g[:, :, 1])).sum(axis=1)
+    assert np.array_equal(cnt[I - tail:], exp)
+    ctx.close()
+    b.close()
