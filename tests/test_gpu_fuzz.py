@@ -91,14 +91,14 @@ def test_random_shapes_mixture_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, s
 
 def draw_cases(n, seed):
     rs = np.random.default_rng(seed)
-    return [(int(rs.integers(3, 400)), int(rs.integers(3, 900)), int(rs.integers(1, 5)), int(rs.integers(1, 33)),
+    return [(int(rs.integers(3, 400)), int(rs.integers(3, 900)), int(rs.integers(1, 5)), int(rs.integers(1, 65)),
              int(rs.integers(0, 5000)), int(rs.integers(1, 1 << 31))) for _ in range(n)]
 
 
 @pytest.mark.parametrize("I,L,ploidy,K,skip,seed", draw_cases(30, 11))
 def test_random_device_draws_vs_host_stream(ctx, I, L, ploidy, K, skip, seed):
     """random_allele_partition drawn on the device = drawn from the oracle's glibc stream on the host, for random sizes,
-    seeds, stream offsets and every K up to 32 (the multiply-shift remainder)."""
+    seeds, stream offsets and every K up to 64 (the multiply-shift remainder)."""
     ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=3, seed=seed % 1000, missing=0.0)
     ctx.set_genotypes(ua, geno)
     ctx.set_model(K, lower_bound=1e-8)
@@ -140,3 +140,43 @@ def test_random_accelerated_fits_batched_vs_cycle_by_cycle(I, L, K, ploidy, sche
     a, b = out
     assert a[:5] == b[:5], (a[:5], b[:5])
     assert np.array_equal(a[5], b[5], equal_nan=True) and np.array_equal(a[6], b[6], equal_nan=True)
+
+
+def variant_cases(n, seed):
+    """round-2 kernel variants: K up to 64, projection off, lower bounds far below the default (reciprocal-per-cell kernels),
+    all-biallelic data (scalar-row individual-side passes from K = 6 / 10)"""
+    rs = np.random.default_rng(seed)
+    sizes = [9, 33, 64, 65, 129, 257, 300, 513]
+    out = []
+    for _ in range(n):
+        K = int(rs.choice([int(rs.integers(1, 13)), int(rs.integers(13, 33)), int(rs.integers(33, 65))], p=[0.5, 0.3, 0.2]))
+        out.append((int(rs.choice(sizes)), int(rs.choice(sizes)), K, int(rs.choice([1, 2, 2, 2, 3, 4])), int(rs.choice([2, 2, 3, 5])),
+                    float(rs.choice([0.0, 0.0, 0.04])), int(rs.choice([1, 1, 0])), float(rs.choice([1e-8, 1e-8, 1e-40, 1e-120])),
+                    int(rs.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,projection,bound,seed", variant_cases(60, 2))
+def test_random_kernel_variants_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, projection, bound, seed):
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=seed, missing=missing)
+    lb = ob.lib.mco_lower_bound(bound, I, ploidy)
+    q0, p0 = random_params(I, ua, K, seed=seed + 1, lower_bound=max(lb, 1e-12))
+    opt = ob.make_options(lower_bound=lb, fused=1, abs_error=0.0, do_projection=projection)
+    mod = ob.Model(ob.Data(I, L, ploidy, ua, geno), opt, K)
+    mod.q(0)[...] = q0
+    mod.p(0)[...] = p0
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, do_projection=projection, lower_bound=lb)
+    ctx.set_q(0, q0)
+    ctx.set_p(0, p0)
+    for s in (1, 2):
+        mod.em_step()
+        ll = ctx.em_step(0, 0)
+        assert abs(ll - mod.logL) <= max(1e-8, 1e-12 * abs(mod.logL)), (s, ll, mod.logL)
+        rtol = 1e-11 if s == 1 else 1e-9
+        np.testing.assert_allclose(ctx.get_q(0), mod.q(0), rtol=rtol, atol=1e-15)
+        np.testing.assert_allclose(ctx.get_p(0), mod.p(0), rtol=rtol, atol=1e-15)
+        np.testing.assert_allclose(ctx.expected_counts(), mod.sik(), rtol=rtol, atol=1e-12)
+    ll_o = mod.loglik(0)
+    assert abs(ctx.loglik(0) - ll_o) <= max(1e-8, 1e-12 * abs(ll_o))
+    assert ctx.loglik_prefetch(0) == ctx.loglik(0)
