@@ -85,6 +85,7 @@ struct mchip_context {
 	hipGraphExec_t cycle_graph[3][5];	/* one captured accelerated cycle per (start slot, scheme) */
 	int *d_cyc;			/* batched accelerated runs: [0] no update this cycle, [1] extrapolation accepted */
 	int have_ll;
+	int ll_parts;			/* partial log likelihoods the last E step left in d_llpart */
 	int s_cache_slot;		/* slot whose S-side sums + logL are held in Spart / d_scalars[2] (mchip_loglik_prefetch), or -1 */
 	/* profiling */
 	int profiling;
@@ -618,11 +619,27 @@ __global__ void k_logp(const double *__restrict__ p, double *__restrict__ out, s
 	out[idx] = (skip_zero && v == 0.0) ? 0.0 : log(v);
 }
 
-/* stop() + stop_condition() + converged() of em_alg.c:101-182 on the device (time limit excepted), one thread */
-__global__ void k_stop_check(mchip_run_state *s, const double *ll)
+/* stop() + stop_condition() + converged() of em_alg.c:101-182 on the device (time limit excepted).  One block: when `part` is
+ * given the block first sums the E step's n partial log likelihoods exactly as k_reduce_sum does (same strided order, same tree:
+ * the batched loops stay bit-identical to the call-by-call ones) and stores the sum in *ll -- one launch less per iteration,
+ * which is what a small data set's step time is made of; then thread 0 applies the rule. */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_stop_check(mchip_run_state *s, double *ll, const double *__restrict__ part = nullptr, int n = 0)
 {
-	if (threadIdx.x || blockIdx.x || s->stopped) return;
-	const double loglik = *ll;
+	__shared__ double red[MCHIP_BLOCK];
+	if (s->stopped) return;		/* uniform */
+	if (part) {
+		double acc = 0.0;
+		for (int x = threadIdx.x; x < n; x += MCHIP_BLOCK) acc += part[x];
+		red[threadIdx.x] = acc;
+		__syncthreads();
+		for (int w = MCHIP_BLOCK / 2; w > 0; w >>= 1) {
+			if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) *ll = red[0];
+	}
+	if (threadIdx.x) return;
+	const double loglik = part ? red[0] : *ll;
 	s->n_iter++;
 	if (loglik != loglik) {
 		s->fatal = 1;
@@ -1366,7 +1383,8 @@ static int finalize_shared_eta(mchip_context *ctx, int to, const int *stop = nul
 }
 
 /* mixture model: E step (mode 0, optionally followed by the M step) or logL_mixture (mode 1) */
-static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int mode, const int *stop = nullptr, int ll_slot = -1)
+static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int mode, const int *stop = nullptr, int ll_slot = -1,
+		       bool defer_ll = false)
 {
 	if (ll_slot < 0) ll_slot = mode ? 1 : 0;	/* d_scalars entry that receives the log likelihood */
 	const size_t KT = (size_t)ctx->K * ctx->T;
@@ -1379,7 +1397,9 @@ static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int m
 	prof_mark(ctx, mode == 0 ? MCHIP_KERN_ACCUM_Q : MCHIP_KERN_LOGLIK, false);
 	const int nb = (ctx->I + MCHIP_BLOCK - 1) / MCHIP_BLOCK;
 	ctx->kt->mix_finalize(ctx->I, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[from], ctx->d_sik, ctx->d_llpart, mode, stop, ctx->stream);
-	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, nb, ctx->d_scalars + ll_slot, stop);
+	ctx->ll_parts = nb;
+	if (!defer_ll)
+		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, nb, ctx->d_scalars + ll_slot, stop);
 	if (do_mstep) {
 		int rc = finalize_shared_eta(ctx, to, stop);		/* em_alg.c:916-962 */
 		if (rc) return rc;
@@ -1399,9 +1419,11 @@ static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int m
 	return MCHIP_OK;
 }
 
-static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const int *stop = nullptr, const int *skip_ind = nullptr)
+/* defer_ll: the caller's k_stop_check sums the partial log likelihoods (ctx->ll_parts of them in d_llpart) itself */
+static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const int *stop = nullptr, const int *skip_ind = nullptr,
+		     bool defer_ll = false)
 {
-	if (!ctx->admixture) return run_mixture(ctx, from, to, do_mstep, 0, stop);
+	if (!ctx->admixture) return run_mixture(ctx, from, to, do_mstep, 0, stop, -1, defer_ll);
 	mchip_pass_args a = pass_args(ctx, from);
 	a.stop = stop;
 	a.skip_ind = skip_ind;
@@ -1418,17 +1440,22 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 		prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
 		ctx->kt->accum_q(a, ctx->stream);
 		prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
-		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart,
-				   ctx->sparse ? ctx->n_ll_ind : ctx->n_ll_col, ctx->d_scalars, stop);
+		ctx->ll_parts = ctx->sparse ? ctx->n_ll_ind : ctx->n_ll_col;
+		if (!defer_ll)
+			hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->ll_parts, ctx->d_scalars, stop);
 	}
 	ctx->s_cache_slot = -1;		/* Spart is consumed below; slot `to` is about to change */
 	const int indiv = ctx->qstride != 0;
-	{
+	if (ctx->n_lchunks <= 16) {
+		/* few slabs (small data sets, where a launch costs as much as the work): k_finalize_q adds them itself, in slab order */
+		ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[from], ctx->qstride,
+				    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream, 0.0);
+	} else {
 		const size_t n = (size_t)ctx->I * ctx->K;
 		hipLaunchKernelGGL(k_sum_slabs, dim3(nblk(n, 32)), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_Spart, ctx->n_lchunks, n, ctx->d_ssum, stop);
+		ctx->kt->finalize_q(ctx->I, ctx->K, 1, ctx->d_ssum, ctx->d_q[from], ctx->qstride,
+				    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream, 0.0);
 	}
-	ctx->kt->finalize_q(ctx->I, ctx->K, 1, ctx->d_ssum, ctx->d_q[from], ctx->qstride,
-			    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream, 0.0);
 	if (do_mstep) {
 		if (!indiv) {
 			int rc = finalize_shared_eta(ctx, to, stop);
@@ -1458,8 +1485,8 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
 	if (use_graph && !ctx->step_graph[slot]) {
 		hipGraph_t graph = nullptr;
 		if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-			rc = run_estep(ctx, slot, slot, 1, stop);
-			hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(64), 0, ctx->stream, ctx->d_run, ctx->d_scalars);
+			rc = run_estep(ctx, slot, slot, 1, stop, nullptr, true);
+			hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_run, ctx->d_scalars, ctx->d_llpart, ctx->ll_parts);
 			const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
 			if (rc || e != hipSuccess || !graph || hipGraphInstantiate(&ctx->step_graph[slot], graph, nullptr, nullptr, 0) != hipSuccess)
 				ctx->step_graph[slot] = nullptr;
@@ -1473,8 +1500,8 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
 			HIPCHK(hipGraphLaunch(ctx->step_graph[slot], ctx->stream));
 			continue;
 		}
-		if ((rc = run_estep(ctx, slot, slot, 1, stop))) return rc;
-		hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(64), 0, ctx->stream, ctx->d_run, ctx->d_scalars);
+		if ((rc = run_estep(ctx, slot, slot, 1, stop, nullptr, true))) return rc;
+		hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_run, ctx->d_scalars, ctx->d_llpart, ctx->ll_parts);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(state, ctx->d_run, sizeof *state, hipMemcpyDeviceToHost, ctx->stream));
@@ -1900,12 +1927,12 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 	const size_t KT = (size_t)ctx->K * ctx->T, nq = (size_t)ctx->nq;
 	int rc;
 	/* em_2_steps (em_alg.c:1072-1211): E(A) M(->B) stop, u = B - A; E(B) M(->C) stop, v = C - B */
-	if ((rc = run_estep(ctx, A, B, 1, stop, cyc + 1))) return rc;
-	hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(64), 0, ctx->stream, ctx->d_run, ctx->d_scalars);
+	if ((rc = run_estep(ctx, A, B, 1, stop, cyc + 1, true))) return rc;
+	hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_run, ctx->d_scalars, ctx->d_llpart, ctx->ll_parts);
 	hipLaunchKernelGGL(k_diff, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[B], ctx->d_p[A], ctx->d_up[0], KT, stop);
 	hipLaunchKernelGGL(k_diff, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[B], ctx->d_q[A], ctx->d_uq[0], nq, stop);
-	if ((rc = run_estep(ctx, B, C, 1, stop, nullptr))) return rc;
-	hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(64), 0, ctx->stream, ctx->d_run, ctx->d_scalars);
+	if ((rc = run_estep(ctx, B, C, 1, stop, nullptr, true))) return rc;
+	hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_run, ctx->d_scalars, ctx->d_llpart, ctx->ll_parts);
 	hipLaunchKernelGGL(k_diff, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[C], ctx->d_p[B], ctx->d_vp[0], KT, stop);
 	hipLaunchKernelGGL(k_diff, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[C], ctx->d_q[B], ctx->d_vq[0], nq, stop);
 	/* emll = log_likelihood(findex = C) -> d_scalars[1] (accel_em.c:53) */
