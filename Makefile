@@ -43,8 +43,13 @@ $(BIN)/multiclust: multiclust_amd/host/mc_main.c $(LIB)/libmulticlust_host.so
 oracle: $(LIB)/libmulticlust_host.so
 	$(MAKE) -C oracle all
 
+# microbenchmarks behind profiles/r01_fp64_microbench.txt and r01_op_cost_microbench.txt (run on the GPU box; binaries are not tracked)
+micro: scripts/micro/fp64_micro scripts/micro/op_cost
+scripts/micro/%: scripts/micro/%.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
+
 clean:
-	rm -rf build $(LIB)/*.so $(BIN)
+	rm -rf build $(LIB)/*.so $(BIN) scripts/micro/fp64_micro scripts/micro/op_cost
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle micro clean
