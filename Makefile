@@ -2,7 +2,7 @@
 HIPCC   ?= /opt/rocm/bin/hipcc
 CC      ?= gcc
 ARCH    ?= gfx950
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Imulticlust_amd/csrc -Wall -Wno-unused-function $(EXTRA)
+HIPFLAGS = --offload-arch=$(ARCH) --offload-compress -O3 -std=c++17 -fPIC -Iinclude -Imulticlust_amd/csrc -Wall -Wno-unused-function $(EXTRA)
 CFLAGS   = -std=gnu11 -O2 -fPIC -Wall -Wextra -Iinclude
 
 OBJ  = build/obj
@@ -28,7 +28,7 @@ $(OBJ)/mchip_comm.o: multiclust_amd/csrc/mchip_comm.hip include/multiclust_hip.h
 
 $(LIB)/libmulticlust_hip.so: $(OBJ)/mchip.o $(OBJ)/mchip_comm.o $(KOBJ)
 	@mkdir -p $(LIB)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
+	$(HIPCC) --offload-arch=$(ARCH) --offload-compress -shared -fPIC -o $@ $^ -ldl
 
 HOST_SRC = $(filter-out multiclust_amd/host/mc_main.c,$(wildcard multiclust_amd/host/*.c))
 $(LIB)/libmulticlust_host.so: $(HOST_SRC) $(wildcard multiclust_amd/host/*.h) include/multiclust_hip.h $(LIB)/libmulticlust_hip.so
