@@ -37,6 +37,7 @@ typedef struct mc_cli_options {
 	int n_gpus;			/* --gpus (extension): shard initialisations over devices device..device+n_gpus-1 */
 	int n_streams;			/* --streams (extension): concurrent fits per device, each with its own context and
 					 * stream; small data sets do not fill a GPU with one fit */
+	const char *pfile, *qfile;	/* -P / -Q: initial parameters of the admixture model from files (read_file.c:880-959) */
 } mc_cli_options;
 
 typedef struct mc_cli_data {

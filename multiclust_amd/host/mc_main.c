@@ -47,6 +47,7 @@ static void usage(FILE *fp, const char *prog)
 		"  -v [level]    verbosity                                --device <n>  HIP device index\n"
 		"  --gpus <n>    shard the initialisations over n GPUs (admixture; one RCCL all-reduce of the results)\n"
 		"  --streams <n> n concurrent fits per GPU, each on its own stream (small data sets do not fill a GPU)\n"
+		"  -P <file> -Q <file>  initial allele frequencies p[k][l][0] (L*K numbers, biallelic loci) and mixing proportions of the admixture model\n"
 		"  --randem      Rand-EM initialisation: the best of -m <n> (50) candidates from random allele centers\n", prog);
 }
 
@@ -142,7 +143,9 @@ static int parse_options(mc_cli_options *o, int argc, const char **argv)
 			else if (!strncmp(w, "pl", 2)) ;	/* --plus: data-writer option */
 			else { if (arg_int(argc, argv, ++i, &v) || v < 1) BAD("-p"); o->ploidy = (int)v; }
 			break;
-		case 'P': case 'Q': case 'A': BAD("-P/-Q/-A side files are not supported by this build");
+		case 'P': if (++i >= argc) BAD("-P"); o->pfile = argv[i]; break;
+		case 'Q': if (++i >= argc) BAD("-Q"); o->qfile = argv[i]; break;
+		case 'A': BAD("-A (partition file for the cluster-comparison indices) is not supported by this build");
 		case 'R': o->R_format = 1; break;
 		case 'r':
 			/* extension: --randem selects the Rand-EM initialisation the reference carries but cannot reach
@@ -262,6 +265,42 @@ static void print_model_state(const mc_cli_options *o, const mc_cli_data *d, con
 }
 
 /* maximize_likelihood (multiclust.c:471-656) for one K */
+/* initialize_model (rnd_init.c:54-89).  With -P and -Q the admixture model starts from the parameters in those files instead
+ * of a random partition (rnd_init.c:74-76): read_qfile (read_file.c:880-922: I*K numbers in i, k order, or K with -c) and
+ * read_pfile (924-959: "assumes biallelic locus": L*K numbers p[k][l][0] in l, k order, p[k][l][1] = 1 - p[k][l][0], any further
+ * allele of a locus keeps what the slot held).  No rand() is consumed, so every initialisation starts from the same point. */
+static int cli_initialize(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, mc_model *mod, mc_rng *rng)
+{
+	if (!(o->em.admixture && o->pfile && o->qfile)) return mc_initialize_model(&o->em, md, mod, rng);
+	const int K = mod->K, nq = o->em.eta_constrained ? K : d->I * K;
+	double *q = malloc(sizeof(double) * (size_t)nq), *p = malloc(sizeof(double) * (size_t)K * d->T);
+	FILE *fq = fopen(o->qfile, "r"), *fp = fopen(o->pfile, "r");
+	int rc = 0;
+	mod->n_iter = 0;
+	mod->logL = -INFINITY;
+	mod->converged = 0;
+	if (o->em.accel_scheme) mod->pindex = mod->tindex = mod->findex = 0;
+	if (!q || !p) rc = MCHIP_ERR_ALLOC;
+	if (!rc && (!fq || !fp)) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: cannot open '%s'\n", fq ? o->pfile : o->qfile); rc = 2; }
+	for (int x = 0; !rc && x < nq; x++)
+		if (fscanf(fq, "%lf", &q[x]) != 1) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: format of '%s'\n", o->qfile); rc = 2; }
+	if (!rc) rc = mc_model_get_p(mod, mod->tindex, p);
+	for (int l = 0; !rc && l < d->L; l++)
+		for (int k = 0; !rc && k < K; k++) {
+			double v;
+			if (fscanf(fp, "%lf", &v) != 1) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: format of '%s'\n", o->pfile); rc = 2; break; }
+			if (d->uniquealleles[l] < 2) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: -P needs two alleles at every locus\n"); rc = 2; break; }
+			p[(size_t)k * d->T + d->toff[l]] = v;
+			p[(size_t)k * d->T + d->toff[l] + 1] = 1 - v;
+		}
+	if (!rc) rc = mc_model_set_q(mod, mod->tindex, q);
+	if (!rc) rc = mc_model_set_p(mod, mod->tindex, p);
+	if (fq) fclose(fq);
+	if (fp) fclose(fp);
+	free(q); free(p);
+	return rc;
+}
+
 static int maximize_likelihood(const mc_cli_options *o, const mc_cli_data *d, const mc_data *md, mc_model *mod, run_state *st, int bootstrap)
 {
 	const int K = mod->K, nq = (o->em.admixture && !o->em.eta_constrained) ? d->I * K : K;
@@ -280,7 +319,7 @@ static int maximize_likelihood(const mc_cli_options *o, const mc_cli_data *d, co
 		mc_reset_model_state(mod);
 		mod->delta_index = delta_keep;
 		mod->start = start;			/* the time limit spans all initialisations (multiclust.c:488) */
-		if ((rc = mc_initialize_model(&o->em, md, mod, &st->rng))) goto DONE;
+		if ((rc = cli_initialize(o, d, md, mod, &st->rng))) goto DONE;
 		mc_em(&o->em, md, mod);
 		if (mod->fatal == MC_FATAL_DEVICE) { rc = MCHIP_ERR_HIP; goto DONE; }
 		if (mod->fatal) exit(0);		/* the reference's reaction to NaN / decreasing logL (em_alg.c:106-120) */
@@ -478,7 +517,8 @@ static int shardable(const mc_cli_options *o)
 	/* MC_FORCE_SHARDED=1 sends even --gpus 1 through the sharded path (threads, jump-ahead, RCCL exchange, replay): the
 	 * single-GPU rehearsal used by tests/test_gpu_cli.py */
 	const int force = getenv("MC_FORCE_SHARDED") != NULL;
-	return (o->n_gpus > 1 || o->n_streams > 1 || (force && o->n_gpus == 1)) && o->em.admixture && !o->target_revisit && !o->target_ll && !o->em.n_seconds;
+	return (o->n_gpus > 1 || o->n_streams > 1 || (force && o->n_gpus == 1)) && o->em.admixture && !o->target_revisit && !o->target_ll && !o->em.n_seconds &&
+	       !(o->pfile && o->qfile);	/* initial parameters from files: every unit would be the same fit */
 }
 
 /* estimate_model (multiclust.c:365-452): K = min_K..max_K, or H0 / HA when bootstrapping */

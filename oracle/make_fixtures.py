@@ -115,8 +115,8 @@ def run_cli(name, stru, args):
     res = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=out, text=True)
     with open(os.path.join(out, "stdout.txt"), "w") as f:
         f.write(res.stdout.replace(stru, os.path.basename(stru)))
-    with open(os.path.join(out, "ARGS.txt"), "w") as f:
-        f.write(" ".join(["-f", os.path.basename(stru)] + args) + "\n")
+    with open(os.path.join(out, "ARGS.txt"), "w") as f:      # files are named by their base names (they live in tests/golden/data)
+        f.write(" ".join(["-f", os.path.basename(stru)] + [os.path.basename(a) if os.path.isabs(a) else a for a in args]) + "\n")
 
 
 def write_interleaved(src, dst, ploidy):
@@ -236,6 +236,24 @@ def main():
     run_cli("multi_admix_k4_i1000_T5", multi, ["-a", "-k", "4", "-r", "7", "-n", "2", "-i", "1000", "-T", "5"])
     run_cli("multi_admix_k4_i1000_T5_s3", multi, ["-a", "-k", "4", "-r", "7", "-n", "2", "-i", "1000", "-T", "5", "-s", "3"])
     run_cli("missing_admix_k3_noproj", miss, ["-a", "-k", "3", "-r", "5", "-n", "2", "--projection"])
+    # -P / -Q: initial parameters from files (read_file.c:880-959; biallelic loci): config 1 from a perturbed copy of its own
+    # first random initialisation, 17 significant digits
+    import struct
+    def f64(path):
+        raw = open(path, "rb").read()
+        return struct.unpack("<%dd" % (len(raw) // 8), raw)
+    g = os.path.join(GOLD, "c1_admix_k3")
+    q0, p0 = f64(os.path.join(g, "q0.f64")), f64(os.path.join(g, "p0.f64"))
+    I, L, K, T = 100, 500, 3, 1000
+    qf, pf = os.path.join(data, "c1_Q.txt"), os.path.join(data, "c1_P.txt")
+    with open(qf, "w") as f:
+        for i in range(I):
+            f.write(" ".join("%.17g" % q0[i * K + k] for k in range(K)) + "\n")
+    with open(pf, "w") as f:
+        for l in range(L):
+            f.write(" ".join("%.17g" % (0.25 + 0.5 * p0[k * T + 2 * l]) for k in range(K)) + "\n")
+    run_cli("c1_admix_k3_PQ", c1, ["-a", "-k", "3", "-r", "1234567", "-n", "1", "-T", "200", "-P", pf, "-Q", qf])
+    run_cli("c1_admix_k3_PQ_s3", c1, ["-a", "-k", "3", "-r", "1234567", "-n", "2", "-s", "3", "-P", pf, "-Q", qf])
 
 
 if __name__ == "__main__":

@@ -21,7 +21,8 @@ def run_cli(case, tmp_path, extra=()):
     gdir = os.path.join(GOLD, "cli_" + case)
     args = open(os.path.join(gdir, "ARGS.txt")).read().split()
     stru = os.path.join(GOLD, "data", args[1])
-    cmd = [BIN, "-f", stru, "-d", str(tmp_path)] + args[2:] + list(extra)
+    rest = [os.path.join(GOLD, "data", a) if os.path.exists(os.path.join(GOLD, "data", a)) else a for a in args[2:]]   # -P / -Q files
+    cmd = [BIN, "-f", stru, "-d", str(tmp_path)] + rest + list(extra)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
     return gdir, CLOCK.sub("HH:MM:SS", res.stdout.replace(stru, os.path.basename(stru)))
@@ -59,6 +60,8 @@ def compare_file(ref, got, atol):
     ("multi_admix_k4_i1000_T5", 2e-6),   # -i beyond the -T cap: one more EM step in the do/while (7 iterations, not 6)
     ("multi_admix_k4_i1000_T5_s3", 2e-6),  # ... one accelerated cycle that stops inside em_2_steps
     ("missing_admix_k3_noproj", 2e-6),   # --projection: the phantom allele slots of loci with missing data keep p = 0
+    ("c1_admix_k3_PQ", 2e-6),            # -P / -Q: initial parameters from files (read_file.c:880-959)
+    ("c1_admix_k3_PQ_s3", 5e-3),
 ])
 def test_cli_matches_reference_binary(case, atol, tmp_path):
     gdir, out = run_cli(case, tmp_path)
