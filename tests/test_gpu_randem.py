@@ -115,3 +115,28 @@ def test_cli_randem_serial_sharded_and_reference_fit(tmp_path, monkeypatch):
     first = re.search(r"initialization = 0: (-?\d+\.\d+) \((\w+ ?\w*)\) in\s+(\d+) iterations", outs[0])
     assert abs(float(first.group(1)) - g.m["randem_run_logL"]) <= 2e-6 and abs(int(first.group(3)) - g.m["randem_run_n_iter"]) <= 1
     assert outs[0] == outs[1]
+
+
+def test_cli_randem_with_bootstrap_and_mixture(tmp_path, monkeypatch):
+    """--randem together with -b (the replicates' fits initialise from the observed haplotypes, candidates included: the
+    reference's random_allele_center reads dat->IL) and for the mixture model: the runs complete, and sharding the
+    initialisations inside each replicate prints what the serial loop prints."""
+    stru = os.path.join(GOLD, "data", "multi.stru")
+    outs = []
+    for sharded in (0, 1):
+        monkeypatch.delenv("MC_FORCE_SHARDED", raising=False)
+        extra = []
+        if sharded:
+            monkeypatch.setenv("MC_FORCE_SHARDED", "1")
+            extra = ["--gpus", "1"]
+        res = subprocess.run([BIN, "-f", stru, "-d", str(tmp_path), "-a", "-k", "3", "-r", "5", "-n", "2", "-b", "2", "--randem", "-m", "3", "-T", "30"] + extra,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr
+        assert res.stdout.count("Bootstrap dataset") == 2 and "p-value to reject H0: K=2" in res.stdout
+        outs.append(re.sub(r"\d\d:\d\d:\d\d", "HH:MM:SS", res.stdout))
+    assert outs[0] == outs[1]
+    res = subprocess.run([BIN, "-f", stru, "-d", str(tmp_path), "-k", "3", "-r", "5", "-n", "2", "--randem", "-m", "4"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    g = Golden("multi_mix_k3_randem")           # same file, seed and model; 5 candidates there, 4 here: only the shape of the output
+    assert res.stdout.count("initialization =") == 2 and "converged" in res.stdout
