@@ -26,18 +26,13 @@ static void mixture_centers(const mc_data *dat, int K, mc_rng *rng, int *I_K, in
 		if (assign) memset(I_K, 0, sizeof(int) * (size_t)I);
 		return;
 	}
-	for (int k = 0; k < K; k++) {
-		int flag;
-		center[k] = mc_rand(rng) % I;
-		do {
-			flag = 0;
-			for (int j = 0; j < k; j++)
-				if (center[k] == center[j]) {
-					center[k] = mc_rand(rng) % I;
-					flag = 1;
-					break;
-				}
-		} while (flag == 1);
+	for (int k = 0; k < K; k++) {		/* rejection until distinct: a clash redraws and the comparison starts over (rnd_init.c:206-218) */
+		int c = mc_rand(rng) % I;
+		for (int j = 0; j < k;) {
+			if (center[j] == c) { c = mc_rand(rng) % I; j = 0; }
+			else j++;
+		}
+		center[k] = c;
 	}
 	if (!assign) return;
 	for (int i = 0; i < I; i++) {
@@ -181,20 +176,14 @@ static uint64_t walk_allele_centers(const mc_data *dat, const init_cache *c, int
 			for (int k = 0; k < M; k++) center[k] = k;
 			for (int k = M; k < K; k++) center[k] = -1;
 		} else {
-			for (int k = 0; k < K; k++) {
-				int flag;
-				center[k] = mc_rand(rng) % M;
+			for (int k = 0; k < K; k++) {	/* K distinct slots by rejection, as above (rnd_init.c:530-548) */
+				int pick = mc_rand(rng) % M;
 				pos++;
-				do {
-					flag = 0;
-					for (int j = 0; j < k; j++)
-						if (center[k] == center[j]) {
-							center[k] = mc_rand(rng) % M;
-							pos++;
-							flag = 1;
-							break;
-						}
-				} while (flag == 1);
+				for (int j = 0; j < k;) {
+					if (center[j] == pick) { pick = mc_rand(rng) % M; pos++; j = 0; }
+					else j++;
+				}
+				center[k] = pick;
 			}
 		}
 		uint64_t matched = 0;
