@@ -941,7 +941,19 @@ int mchip_device_info(mchip_context *ctx, char *name, int name_len, int *compute
 }
 
 /* shape of a data set: tables derived from uniquealleles, genotype buffers allocated but not filled */
+static int set_shape_impl(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, int keep_init);
+
 static int set_shape(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, int keep_init = 0)
+{
+	const int rc = set_shape_impl(ctx, I, L, ploidy, ua, keep_init);
+	if (rc == MCHIP_ERR_HIP || rc == MCHIP_ERR_ALLOC) {	/* an allocation that failed half way: no data set, no model */
+		free_model(ctx);
+		free_data(ctx);
+	}
+	return rc;
+}
+
+static int set_shape_impl(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, int keep_init)
 {
 	if (I <= 0 || L <= 0 || ploidy <= 0 || ploidy > 64 || !ua)
 		return fail(ctx, MCHIP_ERR_INVALID, "set_genotypes: bad shape or null pointer%s", nullptr);
@@ -1161,10 +1173,21 @@ int mchip_get_genotypes(mchip_context *ctx, uint8_t *geno)
 	return MCHIP_OK;
 }
 
+static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_constrained, int do_projection,
+			  double eta_lb, double p_lb, int n_secants);
+
 int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constrained, int do_projection,
 		    double eta_lb, double p_lb, int n_secants)
 {
 	if (!ctx) return MCHIP_ERR_INVALID;
+	const int rc = set_model_impl(ctx, K, admixture, eta_constrained, do_projection, eta_lb, p_lb, n_secants);
+	if (rc == MCHIP_ERR_HIP || rc == MCHIP_ERR_ALLOC) free_model(ctx);	/* an allocation that failed half way leaves no model, not a partial one */
+	return rc;
+}
+
+static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_constrained, int do_projection,
+			  double eta_lb, double p_lb, int n_secants)
+{
 	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "set_model before set_genotypes%s", nullptr);
 	if (K < 1) return fail(ctx, MCHIP_ERR_INVALID, "K must be >= 1%s", nullptr);
 	if (K > MCHIP_MAX_K) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "K > MCHIP_MAX_K is not built%s", nullptr);
