@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_simulate_admixture(rng_window base, con
  * whole stream span, from k_draw_partition).  Writes the partition in stream-independent raw order [I][L][pl]. */
 __global__ __launch_bounds__(256) void k_assign_by_centers(const uint8_t *__restrict__ gtA, int I, int L, int pl, int K,
 		const uint8_t *__restrict__ centers, const unsigned long long *__restrict__ draw_offset,
-		const uint8_t *__restrict__ draws, uint8_t *raw)
+		const uint8_t *__restrict__ draws, unsigned long long n_draws, uint8_t *raw, int *bad)
 {
 	const int l = blockIdx.x * 256 + threadIdx.x;
 	if (l >= L) return;
@@ -382,7 +382,11 @@ __global__ __launch_bounds__(256) void k_assign_by_centers(const uint8_t *__rest
 						if (cen[k] == 0xFF) break;	/* center[k] == -1 ends the list (rnd_init.c:562-563) */
 						if (cen[k] == g) { kk = k; break; }
 					}
-				if (kk < 0) kk = (K == 1) ? 0 : draws[next++];	/* K = 1: every copy to cluster 0, nothing drawn */
+				if (kk < 0) {
+					if (K == 1) kk = 0;			/* every copy to cluster 0, nothing drawn */
+					else if (next < n_draws) kk = draws[next++];
+					else { kk = 0; atomicOr(bad, 1); }	/* the host counted other genotypes than the device holds */
+				}
 				raw[((size_t)i * L + l) * pl + b] = (uint8_t)kk;
 			}
 		}
@@ -1782,9 +1786,16 @@ int mchip_init_from_allele_centers(mchip_context *ctx, const uint8_t *centers, c
 	HIPCHK(d_raw.alloc(n));
 	HIPCHK(hipMemcpyAsync(d_cen, centers, (size_t)ctx->L * ctx->K, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(d_off, draw_offset, sizeof(uint64_t) * (size_t)ctx->L, hipMemcpyHostToDevice, ctx->stream));
+	int *d_bad = bad_flag(ctx);
+	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	hipLaunchKernelGGL(k_assign_by_centers, dim3(nblk((size_t)ctx->L)), dim3(256), 0, ctx->stream,
-			   ctx->init_geno_set ? ctx->d_initA : ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, ctx->K, d_cen.p, d_off.p, d_span.p, d_raw.p);
+			   ctx->init_geno_set ? ctx->d_initA : ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, ctx->K, d_cen.p, d_off.p, d_span.p,
+			   (unsigned long long)n_draws, d_raw.p, d_bad);
 	HIPCHK(hipGetLastError());
+	int bad = 0;
+	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	if (bad) return fail(ctx, MCHIP_ERR_INVALID, "allele-center draws run past the stream span: offsets do not match the genotype held%s", nullptr);
 	rc = partition_mstep(ctx, d_raw, to, 1);
 	(void)hipStreamSynchronize(ctx->stream);	/* the temporaries go out of scope */
 	return rc;
