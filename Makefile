@@ -14,9 +14,13 @@ BIN  = multiclust_amd/bin
 
 all: $(LIB)/libmulticlust_hip.so $(LIB)/libmulticlust_host.so $(BIN)/multiclust oracle
 
+# -amdgpu-spill-vgpr-to-agpr=false: with ROCm 7.2's hipcc the kernels that use the whole register file and spill some of it
+# to accumulation registers can come out wrong (k_individual_sparse<4,true,true,false> at K = 52 returned -inf / NaN log
+# likelihoods; found by a fuzz soak, gone with spills to scratch).  Only K > 20 spills at all; K <= 20 is unaffected.
+KFLAGS = -mllvm -amdgpu-spill-vgpr-to-agpr=false
 $(OBJ)/mchip_k%.o: multiclust_amd/csrc/mchip_kernels_k.hip multiclust_amd/csrc/mchip_internal.h include/multiclust_hip.h
 	@mkdir -p $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -DMCHIP_K=$* -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -DMCHIP_K=$* -c $< -o $@
 
 $(OBJ)/mchip.o: multiclust_amd/csrc/mchip.hip multiclust_amd/csrc/mchip_internal.h include/multiclust_hip.h
 	@mkdir -p $(OBJ)

@@ -1,6 +1,8 @@
 """-m gpu: seeded random shapes through the C-ABI against the CPU oracle (fused order): sizes around the tile and block
 edges (8, 64, 128, 256), every ploidy 1..6, K 1..12, 2..7 alleles, with and without missing data, both eta forms, plain EM
 and one SQUAREM-3 cycle's log likelihoods."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,9 @@ import oracle_bind as ob
 from synth import make_dataset, random_params
 
 pytestmark = pytest.mark.gpu
+# MC_FUZZ_SEED / MC_FUZZ_SCALE: other seeds and more cases for occasional soak runs (defaults are what the suite runs)
+SEED_SHIFT = int(os.environ.get("MC_FUZZ_SEED", "0"))
+SCALE = int(os.environ.get("MC_FUZZ_SCALE", "1"))
 
 
 def cases(n, seed):
@@ -30,7 +35,7 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,constrained,seed", cases(120, 20250117))
+@pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,constrained,seed", cases(120 * SCALE, 20250117 + SEED_SHIFT))
 def test_random_shapes_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, constrained, seed):
     ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=seed, missing=missing)
     lb = ob.lib.mco_lower_bound(1e-8, I, ploidy)
@@ -65,7 +70,7 @@ def mixture_cases(n, seed):
              float(rs.choice([0.0, 0.03])), int(rs.integers(0, 1 << 30))) for _ in range(n)]
 
 
-@pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,seed", mixture_cases(24, 7))
+@pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,seed", mixture_cases(24 * SCALE, 7 + SEED_SHIFT))
 def test_random_shapes_mixture_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, seed):
     ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=seed, missing=missing)
     lb = ob.lib.mco_lower_bound(1e-8, I, ploidy)
@@ -95,7 +100,7 @@ def draw_cases(n, seed):
              int(rs.integers(0, 5000)), int(rs.integers(1, 1 << 31))) for _ in range(n)]
 
 
-@pytest.mark.parametrize("I,L,ploidy,K,skip,seed", draw_cases(30, 11))
+@pytest.mark.parametrize("I,L,ploidy,K,skip,seed", draw_cases(30 * SCALE, 11 + SEED_SHIFT))
 def test_random_device_draws_vs_host_stream(ctx, I, L, ploidy, K, skip, seed):
     """random_allele_partition drawn on the device = drawn from the oracle's glibc stream on the host, for random sizes,
     seeds, stream offsets and every K up to 64 (the multiply-shift remainder)."""
@@ -119,7 +124,7 @@ def accel_cases(n, seed):
             for _ in range(n)]
 
 
-@pytest.mark.parametrize("I,L,K,ploidy,scheme,missing,max_iter,seed", accel_cases(16, 5))
+@pytest.mark.parametrize("I,L,K,ploidy,scheme,missing,max_iter,seed", accel_cases(16 * SCALE, 5 + SEED_SHIFT))
 def test_random_accelerated_fits_batched_vs_cycle_by_cycle(I, L, K, ploidy, scheme, missing, max_iter, seed, monkeypatch):
     """Whole accelerated fits (-s 1..4) from the same random initialisation: device-side batches of cycles against the
     cycle-by-cycle host loop, bit for bit, with and without an iteration cap that can fire inside a cycle."""
@@ -156,7 +161,7 @@ def variant_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,projection,bound,seed", variant_cases(60, 2))
+@pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,projection,bound,seed", variant_cases(60 * SCALE, 2 + SEED_SHIFT))
 def test_random_kernel_variants_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, projection, bound, seed):
     ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=seed, missing=missing)
     lb = ob.lib.mco_lower_bound(bound, I, ploidy)

@@ -343,3 +343,24 @@ def test_em_on_bootstrap_replicate_lacking_alleles(ctx, name):
     if not g.m["do_projection"]:
         absent = counts_of(sim, g.ua).sum(axis=0) == 0
         assert np.all(ctx.get_p(0)[:, absent] == 0.0)
+
+
+@pytest.mark.parametrize("ploidy", [2, 3, 4])
+@pytest.mark.parametrize("bound,projection", [(1e-40, 1), (1e-8, 0), (1e-8, 1)])
+def test_every_K_both_individual_side_variants_agree(ctx, ploidy, bound, projection):
+    """K = 1..64 in every individual-side kernel family (general / reciprocal-per-cell, diploid / tetraploid / generic ploidy):
+    the accumulating pass (E step) and the stand-alone log-likelihood pass are different template instances and must return
+    the same log likelihood.  A fuzz soak found one instance (tetraploid, reciprocal-per-cell, K = 52) that hipcc 7.2
+    miscompiled when it spilled vector registers to accumulation registers (-inf / NaN); the kernel objects are built with
+    -amdgpu-spill-vgpr-to-agpr=false since."""
+    for K in range(1, 65):
+        I, L = 64, 40
+        ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=3, seed=5, missing=0.02)
+        lb = ob.lib.mco_lower_bound(bound, I, ploidy)
+        q0, p0 = random_params(I, ua, K, seed=6, lower_bound=max(lb, 1e-12))
+        ctx.set_genotypes(ua, geno)
+        ctx.set_model(K, lower_bound=lb, do_projection=projection)
+        ctx.set_q(0, q0)
+        ctx.set_p(0, p0)
+        a, b = ctx.loglik(0), ctx.e_step(0)
+        assert np.isfinite(a) and a == b, (K, a, b)
