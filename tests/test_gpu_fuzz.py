@@ -185,3 +185,69 @@ def test_random_kernel_variants_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, 
     ll_o = mod.loglik(0)
     assert abs(ctx.loglik(0) - ll_o) <= max(1e-8, 1e-12 * abs(ll_o))
     assert ctx.loglik_prefetch(0) == ctx.loglik(0)
+
+
+def sim_cases(n, seed):
+    rs = np.random.default_rng(seed)
+    return [(int(rs.integers(5, 300)), int(rs.integers(5, 700)), int(rs.choice([1, 2, 2, 3, 4, 6])), int(rs.choice([1, 2, 3, 5, 8, 13, 33, 64])),
+             int(rs.integers(0, 2)), int(rs.integers(0, 3000)), int(rs.integers(1, 1 << 30))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("I,L,ploidy,K,constrained,skip,seed", sim_cases(12 * SCALE, 3 + SEED_SHIFT))
+def test_random_bootstrap_data_sets_device_vs_host(ctx, I, L, ploidy, K, constrained, skip, seed):
+    """parametric_bootstrap_admixture (bootstrap.c:84-124) generated on the device from the stream's window against the host
+    generator (pinned to the reference's own data sets by tests/test_bootstrap_cpu.py), byte for byte, for random shapes,
+    ploidies, K up to 64, both eta forms and stream offsets."""
+    import ctypes as C
+    from multiclust_amd import host
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=5, seed=seed % 9973, missing=0.02)
+    lb = ob.lib.mco_lower_bound(1e-8, I, ploidy)
+    q, p = random_params(I, ua, K, seed=seed % 7919, lower_bound=lb)
+    q[::3, 0] = lb
+    q /= q.sum(axis=1, keepdims=True)
+    if constrained:
+        q = np.ascontiguousarray(q[0])
+    lib = host.load()
+    opt = host.McOptions()
+    lib.mc_make_options(C.byref(opt))
+    opt.admixture, opt.eta_constrained = 1, constrained
+    ua32 = np.ascontiguousarray(ua, dtype=np.int32)
+    geno = np.ascontiguousarray(geno)
+    dat = host.McData(I, L, ploidy, ua32.ctypes.data, geno.ctypes.data)
+    rng = host.McRng()
+    lib.mc_srand(C.byref(rng), seed)
+    for _ in range(skip):
+        lib.mc_rand(C.byref(rng))
+    gen = host.McSimulation()
+    rng_dev = host.McRng.from_buffer_copy(rng)
+    lib.mc_simulation_begin(C.byref(gen), C.byref(opt), C.byref(dat), K, q.ctypes.data, p.ctypes.data, C.byref(rng_dev))
+    ref = np.empty((I, L, ploidy), dtype=np.uint8)
+    lib.mc_bootstrap_genotypes(C.byref(opt), C.byref(dat), K, q.ctypes.data, p.ctypes.data, C.byref(rng), ref.ctypes.data)
+    assert lib.mc_rand(C.byref(rng)) == lib.mc_rand(C.byref(rng_dev))
+    ctx.simulate_genotypes(I, L, ploidy, ua, np.array(gen.window, dtype=np.uint32), K, q, p, eta_constrained=constrained)
+    assert np.array_equal(ctx.get_genotypes(), ref)
+
+
+def randem_cases(n, seed):
+    rs = np.random.default_rng(seed)
+    return [(int(rs.integers(20, 260)), int(rs.integers(20, 500)), int(rs.choice([1, 2, 2, 3, 4])), int(rs.choice([1, 2, 3, 4, 6, 9, 17, 40])),
+             int(rs.choice([2, 3, 5, 12, 30])), float(rs.choice([0.0, 0.03])), int(rs.integers(0, 2)), int(rs.integers(1, 1 << 30))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("I,L,ploidy,K,maxal,missing,constrained,seed", randem_cases(12 * SCALE, 4 + SEED_SHIFT))
+def test_random_randem_initialisations_vs_oracle(I, L, ploidy, K, maxal, missing, constrained, seed):
+    """Rand-EM (host walk of the loci + device assignment, counts and scoring) against the oracle's serial restatement: same
+    winner and parameters (ratios of small integers: identical), same stream position, for random shapes, K and allele counts
+    on both sides of K (loci with fewer alleles than clusters draw nothing, the others draw centers with retries)."""
+    from multiclust_amd import host
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=seed % 9973, missing=missing)
+    fit = host.Fit(ua, geno, K, admixture=1, eta_constrained=constrained, verbosity=1, initialization_procedure=1, n_rand_em_init=2)
+    rng = fit.initialize(seed)
+    opt = ob.make_options(eta_constrained=constrained, lower_bound=fit.opt.lower_bound, fused=1)
+    mod = ob.Model(ob.Data(I, L, ploidy, ua, geno), opt, K)
+    org, ll = mod.init_randem(seed, 2)
+    assert fit.lib.mc_rand(rng) == ob.lib.mco_rand(org)
+    if abs(ll[0] - ll[1]) > 1e-6 * abs(ll[0]) or K == 1:      # (a near-tie between the two candidates could go either way)
+        np.testing.assert_allclose(fit.get_q(0), mod.q(0), rtol=1e-15, atol=0)
+        np.testing.assert_allclose(fit.get_p(0), mod.p(0), rtol=1e-15, atol=0)
+    fit.close()
