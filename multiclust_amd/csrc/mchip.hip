@@ -64,6 +64,11 @@ struct mchip_context {
 	uint8_t *d_draw;		/* device-drawn partition in stream order [I][L][ploidy], padded to whole chunks */
 	uint32_t *d_jump_hi, *d_jump_lo;	/* jump polynomials of the rand() stream (mchip_mstep_from_rand_partition) */
 	size_t n_jump_hi;
+	/* jump polynomials of the tiled generators (0: bootstrap data set, 1: random partition): x^(A*i), i < nA, stored [31][nA]
+	 * (one per individual) and x^(B*r), r < nB, stored [nB][31] (one per locus tile); kept while A, nA, B, nB stay the same */
+	struct lattice { uint32_t *d_i, *d_r; uint64_t A, B; unsigned nA, nB; } lat[2];
+	uint32_t *d_part_slabs;		/* tiled random partition: packed 16-bit N-side counts per block of 256 individuals */
+	size_t part_slab_bytes;
 	/* model */
 	int K, admixture, constrained, do_projection, nsec, nq, qstride;
 	double eta_lb, p_lb;
@@ -228,11 +233,10 @@ constexpr int RNG_CHUNK = 4 * RNG_LAG * 32;	/* draws (= bytes written) per threa
 
 struct rng_window { uint32_t s[2 * RNG_LAG - 1]; };	/* x_{j-31} .. x_{j+29}: window, then its next 30 values */
 
-/* window (31 words behind the first draw) of the thread whose chunk starts 256*hi_index + threadIdx.x chunks into the
- * stream: jump polynomial = hi(x) * lo(x) mod (x^31 - x^28 - 1); hi is block-uniform (scalar loads), lo is stored
- * [31][256] so that lanes read consecutive words */
-__device__ __forceinline__ void rng_thread_window(const rng_window &base, const uint32_t *__restrict__ jump_hi,
-		const uint32_t *__restrict__ jump_lo, uint32_t (&w)[RNG_LAG])
+/* window (31 words behind the first draw) of a thread whose first draw lies n draws into the stream, x^n = hi(x) * lo(x)
+ * mod (x^31 - x^28 - 1): hi is wave-uniform (scalar loads), lo is stored [31][lo_stride] so that lanes read consecutive words */
+__device__ __forceinline__ void rng_window_at(const rng_window &base, const uint32_t *__restrict__ hi,
+		const uint32_t *__restrict__ lo_table, size_t lo_stride, size_t lo_index, uint32_t (&w)[RNG_LAG])
 {
 	uint32_t t[2 * RNG_LAG - 1];
 #pragma unroll
@@ -240,8 +244,7 @@ __device__ __forceinline__ void rng_thread_window(const rng_window &base, const 
 	{
 		uint32_t lo[RNG_LAG];
 #pragma unroll
-		for (int j = 0; j < RNG_LAG; j++) lo[j] = jump_lo[j * 256 + threadIdx.x];
-		const uint32_t *hi = jump_hi + (size_t)blockIdx.x * RNG_LAG;
+		for (int j = 0; j < RNG_LAG; j++) lo[j] = lo_table[j * lo_stride + lo_index];
 #pragma unroll
 		for (int i = 0; i < RNG_LAG; i++) {
 			const uint32_t h = hi[i];
@@ -262,6 +265,14 @@ __device__ __forceinline__ void rng_thread_window(const rng_window &base, const 
 		for (int j = 0; j < RNG_LAG; j++) v += t[j] * base.s[e + j];
 		w[e] = v;
 	}
+}
+
+/* the thread whose chunk starts 256*blockIdx.x + threadIdx.x chunks of RNG_CHUNK draws into the stream: hi = x^(256*CHUNK*block),
+ * lo = x^(CHUNK*thread) */
+__device__ __forceinline__ void rng_thread_window(const rng_window &base, const uint32_t *__restrict__ jump_hi,
+		const uint32_t *__restrict__ jump_lo, uint32_t (&w)[RNG_LAG])
+{
+	rng_window_at(base, jump_hi + (size_t)blockIdx.x * RNG_LAG, jump_lo, 256, threadIdx.x, w);
 }
 
 __global__ __launch_bounds__(256) void k_draw_partition(rng_window base, const uint32_t *__restrict__ jump_hi,
@@ -292,13 +303,72 @@ __global__ __launch_bounds__(256) void k_draw_partition(rng_window base, const u
 
 /* parametric_bootstrap_admixture (bootstrap.c:84-124) on the device.  Allele copy j (i, l, n order) takes draws 2j
  * (source cluster: inverse-CDF walk over the individual's eta) and 2j+1 (allele: walk over p[k][l][.]) of the rand()
- * stream, r = rand() / RAND_MAX in double and the same left-to-right partial sums, so the decisions are the
- * reference's.  Every copy is simulated (in the default build the "missing stays missing" count is overwritten before
- * it is used, bootstrap.c:87-96).  Thread c owns RNG_CHUNK consecutive draws = RNG_CHUNK/2 copies; its generator
- * window lives in LDS ([31][256]: word e of all lanes is one conflict-free row) so the loop stays compact. */
+ * stream, r = rand() / RAND_MAX in double.  The reference's walk `while (k < K && r > sum) sum += eta[k++]; if (k) k--;`
+ * stops at the largest k whose left-to-right partial sum c_k = eta[0] + ... + eta[k-1] lies below r (partial sums of
+ * non-negative terms never decrease), and r > c_k is a statement about the integer the generator returned: v / RAND_MAX,
+ * rounded, never decreases in v, so r > c_k  <=>  v >= V(c_k) with V(c) the smallest v whose quotient exceeds c.
+ * k_walk_tables finds every V once per call -- with the same double additions and the same division the reference executes
+ * per copy -- and the per-copy work is integer compares against those thresholds: no running sums, no divisions, and none
+ * of a copy's loads waits for another.  Every copy is simulated (in the default build the "missing stays missing" count is
+ * overwritten before it is used, bootstrap.c:87-96). */
+constexpr int SIM_QW = 8, SIM_PW = 4;	/* widths of the padded threshold rows of the FAST form (K <= 8, at most 4 alleles per locus) */
+
+/* smallest v in [0, 2^31] with (double)v / RAND_MAX > c (2^31: no value of rand() does) */
+__device__ uint32_t walk_threshold(double c)
+{
+	const double D = 2147483647.0;
+	if (!(c < 2.0)) return 0x80000000u;	/* v / D <= 1 < 2; also +inf (padding) and NaN */
+	double g = c * D - 2.0;
+	uint32_t v = g > 0.0 ? (uint32_t)g : 0u;	/* c < 2: g < 2^32 */
+	if (v > 0x80000000u) v = 0x80000000u;
+	while (v > 0u && (double)(v - 1u) / D > c) v--;
+	while (v < 0x80000000u && !((double)v / D > c)) v++;
+	return v;
+}
+
+/* thq[i][j] = V(q[i][0] + ... + q[i][j-1]) (j < K; rows of SIM_QW padded with 2^31 when fast); thp[k][c0 + m] =
+ * V(p[k][c0] + ... + p[k][c0 + m - 1]), or rows of SIM_PW per (k, l), padded, when fast */
+__global__ void k_walk_tables(int n_qrows, int K, int L, int T, const int32_t *__restrict__ toff, const double *__restrict__ q,
+			      const double *__restrict__ p, int fast, uint32_t *thq, uint32_t *thp)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx < (size_t)n_qrows) {
+		const double *src = q + idx * K;
+		uint32_t *dst = thq + idx * (size_t)(fast ? SIM_QW : K);
+		double sum = 0.0;
+		for (int j = 0; j < K; j++) { dst[j] = walk_threshold(sum); sum += src[j]; }
+		if (fast) for (int j = K; j < SIM_QW; j++) dst[j] = 0x80000000u;
+	}
+	if (idx < (size_t)K * L) {
+		const int l = (int)(idx % L), k = (int)(idx / L);
+		const int c0 = toff[l], M = toff[l + 1] - c0;
+		const double *src = p + (size_t)k * T + c0;
+		uint32_t *dst = fast ? thp + idx * SIM_PW : thp + (size_t)k * T + c0;
+		double sum = 0.0;
+		for (int m = 0; m < M; m++) { dst[m] = walk_threshold(sum); sum += src[m]; }
+		if (fast) for (int m = M; m < SIM_PW; m++) dst[m] = 0x80000000u;
+	}
+}
+
+/* largest j in [0, n) with v >= tab[j], 0 if there is none (tab never decreases) */
+__device__ __forceinline__ int walk_search(const uint32_t *__restrict__ tab, int n, uint32_t v)
+{
+	int lo = 0;
+	while (n > 1) {
+		const int half = n >> 1;
+		if (v >= tab[lo + half]) lo += half;
+		n -= half;
+	}
+	return lo;
+}
+
+/* Thread c owns RNG_CHUNK consecutive draws = RNG_CHUNK/2 copies; its generator window lives in LDS ([31][256]: word e of
+ * all lanes is one conflict-free row).  Four copies (one output word) are in flight at a time: eight draws, then the four
+ * cluster searches, then the four allele searches, so that the loads of the four overlap. */
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_simulate_admixture(rng_window base, const uint32_t *__restrict__ jump_hi,
-		const uint32_t *__restrict__ jump_lo, size_t n_chunks, size_t n_copies, int L, int pl, int K, int T,
-		const int32_t *__restrict__ toff, const double *__restrict__ q, int qstride, const double *__restrict__ p,
+		const uint32_t *__restrict__ jump_lo, size_t n_chunks, int I, int L, int pl, int K, int T,
+		const int32_t *__restrict__ toff, const uint32_t *__restrict__ thq, int per_individual, const uint32_t *__restrict__ thp,
 		uint32_t *out)
 {
 	__shared__ uint32_t ring[RNG_LAG * 256];
@@ -311,48 +381,300 @@ __global__ __launch_bounds__(256) void k_simulate_admixture(rng_window base, con
 		for (int e = 0; e < RNG_LAG; e++) ring[e * 256 + threadIdx.x] = w[e];
 	}
 	int e = 0;
-	auto next = [&]() -> double {
+	auto next = [&]() -> uint32_t {
 		const int e3 = e >= 3 ? e - 3 : e + RNG_LAG - 3;
 		const uint32_t x = ring[e * 256 + threadIdx.x] + ring[e3 * 256 + threadIdx.x];	/* x_{j-31} + x_{j-3} */
 		ring[e * 256 + threadIdx.x] = x;
 		e = e + 1 == RNG_LAG ? 0 : e + 1;
-		return (double)(x >> 1) / 2147483647.0;		/* rand() / RAND_MAX */
+		return x >> 1;		/* rand() */
 	};
 	constexpr int COPIES = RNG_CHUNK / 2;
-	size_t j = c * COPIES;
+	const size_t j0 = c * COPIES;
 	const size_t per_i = (size_t)L * pl;
-	size_t i = j / per_i;
-	int l = (int)((j % per_i) / pl), a = (int)(j % pl);
+	int i = (int)(j0 / per_i);	/* <= I; copies past the data set's end are clamped to the last individual */
+	int l = (int)((j0 % per_i) / pl), a = (int)(j0 % pl);
 	uint32_t *dst = out + c * (COPIES / 4);
+	const int qrow = FAST ? SIM_QW : K;
 	for (int x = 0; x < COPIES / 4; x++) {
-		uint32_t word = 0;
+		uint32_t v1[4], v2[4];
+		int ci[4], cl[4], k[4];
+#pragma unroll
 		for (int y = 0; y < 4; y++) {
-			const double r1 = next();
-			const double r2 = next();
-			unsigned m = 0;
-			if (j < n_copies) {
-				const double *qi = q + i * (size_t)qstride;
-				int k = 0;
-				double sum = 0;
-				while (k < K && r1 > sum) sum += qi[k++];
-				if (k) k--;
-				const int c0 = toff[l], M = toff[l + 1] - c0;
-				const double *pk = p + (size_t)k * T + c0;
-				int mm = 0;
-				sum = 0;
-				while (mm < M && r2 > sum) sum += pk[mm++];
-				if (mm) mm--;
-				m = (unsigned)mm;
-			}
-			word |= m << (8 * y);
-			j++;
+			v1[y] = next();
+			v2[y] = next();
+			ci[y] = i < I ? i : I - 1;
+			cl[y] = l;
 			if (++a == pl) {
 				a = 0;
 				if (++l == L) { l = 0; i++; }
 			}
 		}
+#pragma unroll
+		for (int y = 0; y < 4; y++) {
+			const uint32_t *tab = thq + (per_individual ? (size_t)ci[y] * qrow : 0);
+			if (FAST) {
+				const uint4 t0 = *reinterpret_cast<const uint4 *>(tab), t1 = *reinterpret_cast<const uint4 *>(tab + 4);
+				k[y] = (v1[y] >= t0.y) + (v1[y] >= t0.z) + (v1[y] >= t0.w) + (v1[y] >= t1.x) + (v1[y] >= t1.y) + (v1[y] >= t1.z) +
+				       (v1[y] >= t1.w);		/* t0.x = V(0): k = 0 either way */
+			} else {
+				k[y] = walk_search(tab, K, v1[y]);
+			}
+		}
+		uint32_t word = 0;
+#pragma unroll
+		for (int y = 0; y < 4; y++) {
+			int m;
+			if (FAST) {
+				const uint4 t = *reinterpret_cast<const uint4 *>(thp + ((size_t)k[y] * L + cl[y]) * SIM_PW);
+				m = (v2[y] >= t.y) + (v2[y] >= t.z) + (v2[y] >= t.w);
+			} else {
+				const int c0 = toff[cl[y]], M = toff[cl[y] + 1] - c0;
+				m = walk_search(thp + (size_t)k[y] * T + c0, M, v2[y]);
+			}
+			word |= (uint32_t)m << (8 * y);
+		}
 		dst[x] = word;
 	}
+}
+
+/* out[j * sj + n * sn] = coefficient j of x^(A*n) mod (x^31 - x^28 - 1), n < count, from pow2[b] = x^(A * 2^b): the jump
+ * polynomials of a regular lattice of stream positions, computed once per data-set shape */
+__global__ void k_jump_powers(const uint32_t *__restrict__ pow2, unsigned count, size_t sj, size_t sn, uint32_t *out)
+{
+	const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+	if (n >= count) return;
+	uint32_t acc[RNG_LAG];
+	for (int j = 0; j < RNG_LAG; j++) acc[j] = j == 0;
+	for (int b = 0; b < 32 && (n >> b); b++) {
+		if (!((n >> b) & 1u)) continue;
+		uint32_t t[2 * RNG_LAG - 1];
+		for (int d = 0; d < 2 * RNG_LAG - 1; d++) t[d] = 0;
+		for (int i = 0; i < RNG_LAG; i++)
+			for (int j = 0; j < RNG_LAG; j++) t[i + j] += acc[i] * pow2[b * RNG_LAG + j];
+		for (int d = 2 * RNG_LAG - 2; d >= RNG_LAG; d--) {
+			t[d - 3] += t[d];
+			t[d - RNG_LAG] += t[d];
+		}
+		for (int j = 0; j < RNG_LAG; j++) acc[j] = t[j];
+	}
+	for (int j = 0; j < RNG_LAG; j++) out[j * sj + n * sn] = acc[j];
+}
+
+/* The same data set generated tile by tile (FAST form: K <= 8, at most 4 alleles per locus, ploidy <= 8): workgroup = 256
+ * individuals x the `tile_loci` loci from blockIdx.x * tile_loci on.  Thread = individual i: its draws for the tile start
+ * 2 * (i * L * PL + l0 * PL) into the stream, x^that = jump_i[i] * jump_r[blockIdx.x] (k_jump_powers).  The allele
+ * thresholds of the tile's loci are staged in LDS ([locus][k][3]: the 64 lanes are at the same locus and differ in k only), the
+ * individual's own cluster thresholds sit in registers, and the copies go straight into the two device layouts (gtS: the
+ * thread's 8 loci x PL bytes are one contiguous run, runs of consecutive individuals adjacent; gtA: PL bytes per locus, 8
+ * consecutive lanes adjacent) -- no raw [I][L][PL] intermediate and no gather from global memory.  tile_loci % 8 == 0. */
+template <int PL>
+__global__ __launch_bounds__(256) void k_simulate_tile(rng_window base, const uint32_t *__restrict__ jump_i,
+		const uint32_t *__restrict__ jump_r, int I, int L, int K, int tile_loci, const uint32_t *__restrict__ thq,
+		int per_individual, const uint32_t *__restrict__ thp, uint8_t *__restrict__ gtA, uint8_t *__restrict__ gtS)
+{
+	extern __shared__ uint32_t sim_lds[];
+	uint32_t *ring = sim_lds, *tile = sim_lds + RNG_LAG * 256;
+	const int l0 = blockIdx.x * tile_loci;
+	const int nl = L - l0 < tile_loci ? L - l0 : tile_loci;
+	const int i = blockIdx.y * 256 + threadIdx.x;
+	for (int idx = threadIdx.x; idx < K * nl; idx += 256) {
+		const int k = idx / nl, ll = idx - k * nl;
+		const uint4 t = *reinterpret_cast<const uint4 *>(thp + ((size_t)k * L + l0 + ll) * SIM_PW);
+		uint32_t *dst = tile + ((size_t)ll * K + k) * 3;
+		dst[0] = t.y; dst[1] = t.z; dst[2] = t.w;	/* t.x = V(0): allele 0 either way */
+	}
+	__syncthreads();
+	if (i >= ((I + 7) & ~7)) return;
+	uint8_t *colA = gtA + ((((size_t)(i >> 3) * L + l0) * 8) + (i & 7)) * PL;	/* + ll * 8 * PL per locus */
+	if (i >= I) {		/* rows that pad the last block of 8 individuals */
+		for (int ll = 0; ll < nl; ll++)
+#pragma unroll
+			for (int a = 0; a < PL; a++) colA[(size_t)ll * 8 * PL + a] = MCHIP_MISSING;
+		return;
+	}
+	{
+		uint32_t w[RNG_LAG];
+		rng_window_at(base, jump_r + (size_t)blockIdx.x * RNG_LAG, jump_i, (size_t)I, (size_t)i, w);
+#pragma unroll
+		for (int e = 0; e < RNG_LAG; e++) ring[e * 256 + threadIdx.x] = w[e];
+	}
+	int e = 0;
+	auto next = [&]() -> uint32_t {
+		const int e3 = e >= 3 ? e - 3 : e + RNG_LAG - 3;
+		const uint32_t x = ring[e * 256 + threadIdx.x] + ring[e3 * 256 + threadIdx.x];	/* x_{j-31} + x_{j-3} */
+		ring[e * 256 + threadIdx.x] = x;
+		e = e + 1 == RNG_LAG ? 0 : e + 1;
+		return x >> 1;		/* rand() */
+	};
+	uint32_t tq[SIM_QW - 1];
+	{
+		const uint32_t *row = thq + (per_individual ? (size_t)i * SIM_QW : 0);
+		const uint4 t0 = *reinterpret_cast<const uint4 *>(row), t1 = *reinterpret_cast<const uint4 *>(row + 4);
+		tq[0] = t0.y; tq[1] = t0.z; tq[2] = t0.w; tq[3] = t1.x; tq[4] = t1.y; tq[5] = t1.z; tq[6] = t1.w;
+	}
+	for (int g = 0; g * 8 < nl; g++) {
+		unsigned long long run[PL];	/* the 8 * PL bytes of this individual's gtS group */
+#pragma unroll
+		for (int x = 0; x < PL; x++) run[x] = ~0ull;
+#pragma unroll
+		for (int t = 0; t < 8; t++) {
+			const int ll = g * 8 + t;
+			if (ll < nl) {		/* uniform */
+				uint32_t v1[PL], v2[PL];
+#pragma unroll
+				for (int a = 0; a < PL; a++) { v1[a] = next(); v2[a] = next(); }
+				unsigned long long bytes = 0;
+#pragma unroll
+				for (int a = 0; a < PL; a++) {
+					int k = 0;
+#pragma unroll
+					for (int x = 0; x < SIM_QW - 1; x++) k += v1[a] >= tq[x];
+					const uint32_t *th = tile + ((size_t)ll * K + k) * 3;
+					const unsigned m = (v2[a] >= th[0]) + (v2[a] >= th[1]) + (v2[a] >= th[2]);
+					bytes |= (unsigned long long)m << (8 * a);
+				}
+				uint8_t *dst = colA + (size_t)ll * 8 * PL;
+				if (PL == 4) *reinterpret_cast<uint32_t *>(dst) = (uint32_t)bytes;
+				else if (PL == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)bytes;
+				else if (PL == 8) *reinterpret_cast<unsigned long long *>(dst) = bytes;
+				else {
+#pragma unroll
+					for (int a = 0; a < PL; a++) dst[a] = (uint8_t)(bytes >> (8 * a));
+				}
+#pragma unroll
+				for (int a = 0; a < PL; a++) {
+					constexpr unsigned long long ff = 0xFFull;
+					const int b = t * PL + a;
+					run[b >> 3] = (run[b >> 3] & ~(ff << (8 * (b & 7)))) | (((bytes >> (8 * a)) & ff) << (8 * (b & 7)));
+				}
+			}
+		}
+		unsigned long long *dstS = reinterpret_cast<unsigned long long *>(gtS + (((size_t)(l0 / 8 + g) * I + i) * 8) * PL);
+#pragma unroll
+		for (int x = 0; x < PL; x++) dstS[x] = run[x];
+	}
+}
+
+template <int PL>
+static void launch_simulate_tile(mchip_context *ctx, const rng_window &base, int K, int tile, const uint32_t *thq, int per_individual,
+				 const uint32_t *thp)
+{
+	const unsigned R = (unsigned)((ctx->L + tile - 1) / tile), by = (unsigned)((((ctx->I + 7) & ~7) + 255) / 256);
+	const size_t lds = ((size_t)RNG_LAG * 256 + (size_t)tile * K * 3) * sizeof(uint32_t);
+	hipLaunchKernelGGL(k_simulate_tile<PL>, dim3(R, by), dim3(256), lds, ctx->stream, base, ctx->lat[0].d_i, ctx->lat[0].d_r, ctx->I, ctx->L, K,
+			   tile, thq, per_individual, thp, ctx->d_gtA, ctx->d_gtS);
+}
+
+/* random_allele_partition + the counts of the first M step (rnd_init.c:349-357,456-482) in one pass, nothing stored per copy.
+ * Workgroup = 256 individuals x one locus chunk of the S-side pass (blockIdx.x; its loci taken `tile` at a time); thread =
+ * individual i: copy (i, l, b) takes draw i*L*PL + l*PL + b of the stream, so the thread's draws for the chunk are consecutive
+ * from x^(L*PL*i) * x^(lchunk*PL*blockIdx.x) on (k_jump_powers).  d[i][k][l][m] = 1 for every (allele m, cluster k) pair
+ * some non-missing copy of the individual at the locus was given: the thread drops the repeats among its PL copies, then
+ *   S side: one count per pair into its own packed 16-bit counters in LDS (at most lchunk*PL <= 65535), written as doubles
+ *           to Spart[chunk][i][.] at the end -- what k_partition_individuals writes;
+ *   N side: one LDS atomic per pair into the tile's packed 16-bit counters [column][KP] (at most 256 per workgroup), stored
+ *           per tile into this workgroup's slab; k_partition_finish adds the slabs.  Integer counts: the order of the
+ *           atomics does not matter, the sums are exact.
+ * The genotype comes from gtS (the thread's 8 loci x PL bytes are one contiguous run).  KP = K rounded up to even. */
+template <int PL>
+__global__ __launch_bounds__(256) void k_partition_tile(rng_window base, const uint32_t *__restrict__ jump_i,
+		const uint32_t *__restrict__ jump_r, int I, int L, int K, uint32_t magic, uint32_t shift, int lchunk, int tile,
+		const int32_t *__restrict__ toff, const uint8_t *__restrict__ gtS, uint32_t *__restrict__ slabs, size_t slab_words,
+		double *__restrict__ Spart)
+{
+	extern __shared__ uint32_t part_lds[];
+	const int KP = (K + 1) & ~1;
+	uint32_t *ring = part_lds, *scnt = part_lds + RNG_LAG * 256, *ncnt = scnt + (KP / 2) * 256;
+	const int i = blockIdx.y * 256 + threadIdx.x;
+	const bool live = i < I;
+	const int l_begin = blockIdx.x * lchunk, l_end = L - l_begin < lchunk ? L : l_begin + lchunk;
+	if (live) {
+		uint32_t w[RNG_LAG];
+		rng_window_at(base, jump_r + (size_t)blockIdx.x * RNG_LAG, jump_i, (size_t)I, (size_t)i, w);
+#pragma unroll
+		for (int e = 0; e < RNG_LAG; e++) ring[e * 256 + threadIdx.x] = w[e];
+	}
+	for (int x = 0; x < KP / 2; x++) scnt[x * 256 + threadIdx.x] = 0;
+	int e = 0;
+	auto next = [&]() -> uint32_t {
+		const int e3 = e >= 3 ? e - 3 : e + RNG_LAG - 3;
+		const uint32_t x = ring[e * 256 + threadIdx.x] + ring[e3 * 256 + threadIdx.x];	/* x_{j-31} + x_{j-3} */
+		ring[e * 256 + threadIdx.x] = x;
+		e = e + 1 == RNG_LAG ? 0 : e + 1;
+		const uint32_t v = x >> 1;		/* rand() */
+		return K == 1 ? 0u : v - (__umulhi(v, magic) >> shift) * (uint32_t)K;	/* rand() % K (k_draw_partition) */
+	};
+	uint32_t *slab = slabs + (size_t)blockIdx.y * slab_words;
+	for (int t0 = l_begin; t0 < l_end; t0 += tile) {
+		const int t1 = l_end - t0 < tile ? l_end : t0 + tile;
+		const int col0 = toff[t0], nwords = (toff[t1] - col0) * (KP / 2);
+		for (int x = threadIdx.x; x < nwords; x += 256) ncnt[x] = 0;
+		__syncthreads();
+		if (live)
+			for (int g = t0 >> 3; g * 8 < t1; g++) {
+				unsigned long long run[PL];
+				{
+					const unsigned long long *src = reinterpret_cast<const unsigned long long *>(gtS + (((size_t)g * I + i) * 8) * PL);
+#pragma unroll
+					for (int x = 0; x < PL; x++) run[x] = src[x];
+				}
+#pragma unroll
+				for (int t = 0; t < 8; t++) {
+					const int l = g * 8 + t;
+					if (l < t1) {		/* uniform */
+						const int cl = toff[l] - col0;
+						uint32_t key[PL];
+#pragma unroll
+						for (int b = 0; b < PL; b++) {
+							const int at = t * PL + b;
+							const uint32_t mb = (uint32_t)(run[at >> 3] >> (8 * (at & 7))) & 0xFFu;
+							const uint32_t kb = next();
+							key[b] = mb | (kb << 8);
+							bool count = mb != MCHIP_MISSING;
+#pragma unroll
+							for (int b2 = 0; b2 < b; b2++) count = count && key[b2] != key[b];
+							if (count) {
+								scnt[(kb >> 1) * 256 + threadIdx.x] += 1u << (16 * (kb & 1u));
+								const uint32_t en = (uint32_t)(cl + (int)mb) * (uint32_t)KP + kb;
+								atomicAdd(&ncnt[en >> 1], 1u << (16 * (en & 1u)));
+							}
+						}
+					}
+				}
+			}
+		__syncthreads();
+		uint32_t *dst = slab + (size_t)col0 * (KP / 2);
+		for (int x = threadIdx.x; x < nwords; x += 256) dst[x] = ncnt[x];
+		__syncthreads();
+	}
+	if (live) {
+		double *out = Spart + ((size_t)blockIdx.x * I + i) * K;
+		for (int k = 0; k < K; k++) out[k] = (double)((scnt[(k >> 1) * 256 + threadIdx.x] >> (16 * (k & 1))) & 0xFFFFu);
+	}
+}
+
+/* Apart[0][c][k] = sum over the workgroup slabs of k_partition_tile; thread = (c, k) */
+__global__ void k_partition_finish(const uint32_t *__restrict__ slabs, size_t slab_words, int n_slabs, int T, int K, double *Apart)
+{
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= (size_t)T * K) return;
+	const int k = (int)(idx % K);
+	const size_t c = idx / K;
+	const int KP = (K + 1) & ~1;
+	const size_t en = c * KP + k;
+	unsigned sum = 0;
+	for (int b = 0; b < n_slabs; b++) sum += (slabs[(size_t)b * slab_words + (en >> 1)] >> (16 * (en & 1))) & 0xFFFFu;
+	Apart[idx] = (double)sum;
+}
+
+template <int PL>
+static void launch_partition_tile(mchip_context *ctx, const rng_window &base, uint32_t magic, uint32_t shift, int tile, size_t lds,
+				  const uint8_t *gtS, size_t slab_words)
+{
+	const unsigned by = (unsigned)((ctx->I + 255) / 256);
+	hipLaunchKernelGGL(k_partition_tile<PL>, dim3((unsigned)ctx->n_lchunks, by), dim3(256), lds, ctx->stream, base, ctx->lat[1].d_i,
+			   ctx->lat[1].d_r, ctx->I, ctx->L, ctx->K, magic, shift, ctx->lchunk, tile, ctx->d_toff, gtS, ctx->d_part_slabs, slab_words,
+			   ctx->d_Spart);
 }
 
 /* random_allele_center's assignment (rnd_init.c:552-580) given the centers the host drew: copy (i, a) of locus l goes to the
@@ -836,6 +1158,9 @@ static void free_data(mchip_context *ctx)
 	dfree(ctx->d_initA); dfree(ctx->d_initS);
 	dfree(ctx->d_draw); dfree(ctx->d_jump_hi); dfree(ctx->d_jump_lo);
 	ctx->n_jump_hi = 0;
+	for (int x = 0; x < 2; x++) { dfree(ctx->lat[x].d_i); dfree(ctx->lat[x].d_r); ctx->lat[x].nA = 0; }
+	dfree(ctx->d_part_slabs);
+	ctx->part_slab_bytes = 0;
 	ctx->init_geno_set = 0;
 	ctx->h_ua.clear();
 	ctx->I = ctx->L = ctx->T = 0;
@@ -1027,26 +1352,13 @@ static int stream_buffer(mchip_context *ctx)
 	return MCHIP_OK;
 }
 
-/* genotype held on the device as [I][L][ploidy] bytes -> the kernels' layouts (validated), packed counts */
-static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
+/* gtA / gtS are in place: flags and the packed per-column allele counts of the column pass */
+static int install_layouts(mchip_context *ctx, int has_missing)
 {
 	const int I = ctx->I, L = ctx->L, ploidy = ctx->ploidy, T = ctx->T;
-	int *d_bad = bad_flag(ctx);
-	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
-	if (launch_relayout(ctx->stream, d_raw, I, L, ploidy, ctx->d_ua, 0, ctx->d_gtA, ctx->d_gtS, d_bad))
-		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "data set too large for the layout kernel%s", nullptr);
-	HIPCHK(hipGetLastError());
-	int bad = 0;
-	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-	HIPCHK(hipStreamSynchronize(ctx->stream));
-	if (bad & 1) {
-		free_data(ctx);
-		return fail(ctx, MCHIP_ERR_INVALID, "genotype allele index >= uniquealleles[l]%s", nullptr);
-	}
-	if (ctx->has_missing != ((bad & 2) ? 1 : 0)) drop_graphs(ctx);	/* parked model buffers: the kernel variant changes */
-	ctx->has_missing = (bad & 2) ? 1 : 0;
+	if (ctx->has_missing != has_missing) drop_graphs(ctx);	/* parked model buffers: the kernel variant changes */
+	ctx->has_missing = has_missing;
 	ctx->counts_valid = 0;	/* counted when asked for (mchip_data_counts): a bootstrap replicate never asks */
-	/* packed per-column allele counts for the column pass */
 	ctx->count_bits = ploidy <= 3 ? 2 : (ploidy <= 15 ? 4 : 0);
 	if (getenv("MCHIP_NO_COUNTS")) ctx->count_bits = 0;
 	if (ctx->count_bits) {
@@ -1063,6 +1375,25 @@ static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
 		HIPCHK(hipStreamSynchronize(ctx->stream));
 	}
 	return MCHIP_OK;
+}
+
+/* genotype held on the device as [I][L][ploidy] bytes -> the kernels' layouts (validated), packed counts */
+static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
+{
+	const int I = ctx->I, L = ctx->L, ploidy = ctx->ploidy;
+	int *d_bad = bad_flag(ctx);
+	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+	if (launch_relayout(ctx->stream, d_raw, I, L, ploidy, ctx->d_ua, 0, ctx->d_gtA, ctx->d_gtS, d_bad))
+		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "data set too large for the layout kernel%s", nullptr);
+	HIPCHK(hipGetLastError());
+	int bad = 0;
+	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	if (bad & 1) {
+		free_data(ctx);
+		return fail(ctx, MCHIP_ERR_INVALID, "genotype allele index >= uniquealleles[l]%s", nullptr);
+	}
+	return install_layouts(ctx, (bad & 2) ? 1 : 0);
 }
 
 int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, const uint8_t *geno)
@@ -1603,12 +1934,29 @@ int mchip_loglik_prefetch(mchip_context *ctx, int slot, double *loglik)
 	return MCHIP_OK;
 }
 
+/* the hard-partition counts are in Spart ([n_lchunks][I][K]) and in n_aslabs slabs of Apart: normalise (and project) into slot `to` */
+static int partition_finalize(mchip_context *ctx, int to, int counts, int n_aslabs)
+{
+	int rc;
+	const int indiv = ctx->qstride != 0;
+	const int project = counts ? 0 : ctx->do_projection;
+	const double add = counts ? 1.0 : 0.0;
+	ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[to], ctx->qstride,
+			    ctx->d_q[to], ctx->d_sik, indiv, 0, project, ctx->eta_lb, nullptr, ctx->stream, add);
+	if (!indiv && (rc = finalize_shared_eta(ctx, to, nullptr, add, !counts))) return rc;
+	hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
+			   ctx->L, ctx->K, ctx->T, ctx->d_toff, n_aslabs, ctx->d_Apart, ctx->d_p[to], ctx->d_p[to],
+			   0, add, project, ctx->p_lb, ctx->d_flags);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+
 /* relayout of a partition held on the device in stream order, then the hard-partition M step into slot `to`
  * (counts = 0: random_initialize_admixture, rnd_init.c:349-357), or initialize_parameters_admixture (rnd_init.c:603-705)
  * from that partition (counts = 1: one count per copy on top of 1, normalised, never projected) */
 static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to, int counts = 0)
 {
-	int rc;
 	if (!ctx->d_asA) HIPCHK(hipMalloc((void **)&ctx->d_asA, ctx->geno_bytes_A));
 	if (!ctx->d_asS) HIPCHK(hipMalloc((void **)&ctx->d_asS, ctx->geno_bytes_S));
 	int *d_bad = bad_flag(ctx);
@@ -1629,18 +1977,7 @@ static int partition_mstep(mchip_context *ctx, const uint8_t *d_raw, int to, int
 	a.part_counts = counts;
 	ctx->kt->part_p(a, ctx->stream);
 	ctx->kt->part_q(a, ctx->stream);
-	const int indiv = ctx->qstride != 0;
-	const int project = counts ? 0 : ctx->do_projection;
-	const double add = counts ? 1.0 : 0.0;
-	ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[to], ctx->qstride,
-			    ctx->d_q[to], ctx->d_sik, indiv, 0, project, ctx->eta_lb, nullptr, ctx->stream, add);
-	if (!indiv && (rc = finalize_shared_eta(ctx, to, nullptr, add, !counts))) return rc;
-	hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
-			   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[to], ctx->d_p[to],
-			   0, add, project, ctx->p_lb, ctx->d_flags);
-	HIPCHK(hipGetLastError());
-	HIPCHK(hipStreamSynchronize(ctx->stream));
-	return MCHIP_OK;
+	return partition_finalize(ctx, to, counts, ctx->n_ichunks);
 }
 
 static int check_partition_call(mchip_context *ctx, const void *arg, int to)
@@ -1723,11 +2060,111 @@ static int rng_stream_setup(mchip_context *ctx, const uint32_t *window, size_t n
 	return rng_jump_tables(ctx, *n_blocks);
 }
 
+/* x^e mod (x^31 - x^28 - 1) */
+static void rng_xpow(uint64_t e, uint32_t *out)
+{
+	uint32_t acc[RNG_LAG] = {0}, sq[RNG_LAG] = {0};
+	acc[0] = 1;
+	sq[1] = 1;
+	for (; e; e >>= 1) {
+		if (e & 1) rng_polymul(acc, sq, acc);
+		rng_polymul(sq, sq, sq);
+	}
+	memcpy(out, acc, sizeof acc);
+}
+
+/* d_out[j * sj + n * sn] = coefficient j of x^(A*n), n < count */
+static int rng_lattice_table(mchip_context *ctx, uint64_t A, unsigned count, size_t sj, size_t sn, uint32_t *d_out)
+{
+	uint32_t pw[32 * RNG_LAG];
+	rng_xpow(A, pw);
+	for (int b = 1; b < 32; b++) rng_polymul(pw + (b - 1) * RNG_LAG, pw + (b - 1) * RNG_LAG, pw + b * RNG_LAG);
+	scoped_dev<uint32_t> d_pw;
+	HIPCHK(d_pw.alloc(32 * RNG_LAG));
+	HIPCHK(hipMemcpyAsync(d_pw, pw, sizeof pw, hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(k_jump_powers, dim3(nblk(count)), dim3(256), 0, ctx->stream, d_pw.p, count, sj, sn, d_out);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+
+/* jump polynomials of a tiled generator (see mchip_context::lat): thread (i, r) starts A*i + B*r draws into the stream */
+static int lattice_tables(mchip_context *ctx, int which, uint64_t A, unsigned nA, uint64_t B, unsigned nB)
+{
+	mchip_context::lattice &t = ctx->lat[which];
+	if (t.d_i && t.A == A && t.nA == nA && t.B == B && t.nB == nB) return MCHIP_OK;
+	dfree(t.d_i);
+	dfree(t.d_r);
+	t.nA = 0;
+	HIPCHK(hipMalloc((void **)&t.d_i, (size_t)RNG_LAG * nA * sizeof(uint32_t)));
+	HIPCHK(hipMalloc((void **)&t.d_r, (size_t)RNG_LAG * nB * sizeof(uint32_t)));
+	int rc = rng_lattice_table(ctx, A, nA, (size_t)nA, 1, t.d_i);
+	if (!rc) rc = rng_lattice_table(ctx, B, nB, 1, RNG_LAG, t.d_r);
+	if (rc) return rc;
+	t.A = A; t.nA = nA; t.B = B; t.nB = nB;
+	return MCHIP_OK;
+}
+
+/* v % K through floor(v / K) = (v * magic) >> (31 + l), l = ceil(log2 K), magic = ceil(2^(31+l) / K) < 2^32: exact for every
+ * v < 2^31 (division by an invariant integer); the kernels take the high word, so shift = l - 1.  K >= 2. */
+static void mod_k_magic(int K, uint32_t *magic, uint32_t *shift)
+{
+	uint32_t l = 0;
+	while ((1u << l) < (uint32_t)K) l++;
+	const uint64_t pw = (uint64_t)1 << (31 + l);
+	*magic = (uint32_t)((pw + (uint64_t)K - 1) / (uint64_t)K);
+	*shift = l - 1;
+}
+
+/* the tiled form of the random partition + first M step (k_partition_tile); returns -1 when the shape does not fit it */
+static int rand_partition_tiled(mchip_context *ctx, const uint32_t *window, int to)
+{
+	const int K = ctx->K, KP = (K + 1) & ~1, pl = ctx->ploidy;
+	if (pl > 8 || (size_t)ctx->lchunk * pl > 65535 || getenv("MCHIP_PART_NO_TILE")) return -1;
+	/* N-side counters of a tile: tile * max_M * KP / 2 words, about 16 KiB, a multiple of 8 loci */
+	int tile = (int)((16384 / ((size_t)ctx->max_M * KP * 2)) & ~(size_t)7);
+	if (tile < 8) tile = 8;
+	if (tile > ctx->lchunk) tile = ctx->lchunk;
+	const size_t lds = ((size_t)RNG_LAG * 256 + (size_t)(KP / 2) * 256 + (size_t)tile * ctx->max_M * (KP / 2)) * sizeof(uint32_t);
+	if (lds > 64 * 1024) return -1;
+	int rc;
+	rng_window base;
+	for (int t = 0; t < RNG_LAG; t++) base.s[t] = window[t];
+	for (int t = 0; t < RNG_LAG - 1; t++) base.s[RNG_LAG + t] = base.s[t] + base.s[RNG_LAG - 3 + t];
+	if ((rc = lattice_tables(ctx, 1, (uint64_t)ctx->L * pl, (unsigned)ctx->I, (uint64_t)ctx->lchunk * pl, (unsigned)ctx->n_lchunks))) return rc;
+	const size_t slab_words = (size_t)ctx->T * (KP / 2), n_slabs = (size_t)(ctx->I + 255) / 256;
+	if (ctx->part_slab_bytes < n_slabs * slab_words * sizeof(uint32_t)) {
+		dfree(ctx->d_part_slabs);
+		ctx->part_slab_bytes = 0;
+		HIPCHK(hipMalloc((void **)&ctx->d_part_slabs, n_slabs * slab_words * sizeof(uint32_t)));
+		ctx->part_slab_bytes = n_slabs * slab_words * sizeof(uint32_t);
+	}
+	uint32_t magic = 0, shift = 0;
+	if (K > 1) mod_k_magic(K, &magic, &shift);
+	const uint8_t *gtS = ctx->init_geno_set ? ctx->d_initS : ctx->d_gtS;	/* bootstrap fits: the observed haplotypes (rnd_init.c:471) */
+	switch (pl) {
+	case 1: launch_partition_tile<1>(ctx, base, magic, shift, tile, lds, gtS, slab_words); break;
+	case 2: launch_partition_tile<2>(ctx, base, magic, shift, tile, lds, gtS, slab_words); break;
+	case 3: launch_partition_tile<3>(ctx, base, magic, shift, tile, lds, gtS, slab_words); break;
+	case 4: launch_partition_tile<4>(ctx, base, magic, shift, tile, lds, gtS, slab_words); break;
+	case 5: launch_partition_tile<5>(ctx, base, magic, shift, tile, lds, gtS, slab_words); break;
+	case 6: launch_partition_tile<6>(ctx, base, magic, shift, tile, lds, gtS, slab_words); break;
+	case 7: launch_partition_tile<7>(ctx, base, magic, shift, tile, lds, gtS, slab_words); break;
+	default: launch_partition_tile<8>(ctx, base, magic, shift, tile, lds, gtS, slab_words); break;
+	}
+	HIPCHK(hipGetLastError());
+	hipLaunchKernelGGL(k_partition_finish, dim3(nblk((size_t)ctx->T * K)), dim3(256), 0, ctx->stream, ctx->d_part_slabs, slab_words,
+			   (int)n_slabs, ctx->T, K, ctx->d_Apart);
+	HIPCHK(hipGetLastError());
+	return partition_finalize(ctx, to, 0, 1);
+}
+
 int mchip_mstep_from_rand_partition(mchip_context *ctx, const uint32_t *window, int to)
 {
 	int rc = check_partition_call(ctx, window, to);
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(ctx->device));
+	if ((rc = rand_partition_tiled(ctx, window, to)) >= 0) return rc;
 	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
 	rng_window base;
 	size_t n_chunks, n_blocks;
@@ -1736,14 +2173,10 @@ int mchip_mstep_from_rand_partition(mchip_context *ctx, const uint32_t *window, 
 	if (ctx->K == 1) {
 		HIPCHK(hipMemsetAsync(ctx->d_draw, 0, n, ctx->stream));	/* rand() % 1 */
 	} else {
-		/* v % K through floor(v / K) = (v * magic) >> (31 + l), l = ceil(log2 K), magic = ceil(2^(31+l) / K) < 2^32:
-		 * exact for every v < 2^31 (division by an invariant integer); the kernel takes the high word, so shift = l - 1 */
-		uint32_t l = 0;
-		while ((1u << l) < (uint32_t)ctx->K) l++;
-		const uint64_t pw = (uint64_t)1 << (31 + l);
-		const uint32_t magic = (uint32_t)((pw + (uint64_t)ctx->K - 1) / (uint64_t)ctx->K);
+		uint32_t magic, shift;
+		mod_k_magic(ctx->K, &magic, &shift);
 		hipLaunchKernelGGL(k_draw_partition, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, base, ctx->d_jump_hi,
-				   ctx->d_jump_lo, n_chunks, (uint32_t)ctx->K, magic, l - 1, (uint32_t *)ctx->d_draw);
+				   ctx->d_jump_lo, n_chunks, (uint32_t)ctx->K, magic, shift, (uint32_t *)ctx->d_draw);
 		HIPCHK(hipGetLastError());
 	}
 	return partition_mstep(ctx, ctx->d_draw, to);
@@ -1768,12 +2201,10 @@ int mchip_init_from_allele_centers(mchip_context *ctx, const uint8_t *centers, c
 		if (ctx->K == 1) {
 			HIPCHK(hipMemsetAsync(d_span, 0, n_chunks * RNG_CHUNK, ctx->stream));
 		} else {
-			uint32_t l = 0;
-			while ((1u << l) < (uint32_t)ctx->K) l++;
-			const uint64_t pw = (uint64_t)1 << (31 + l);
-			const uint32_t magic = (uint32_t)((pw + (uint64_t)ctx->K - 1) / (uint64_t)ctx->K);
+			uint32_t magic, shift;
+			mod_k_magic(ctx->K, &magic, &shift);
 			hipLaunchKernelGGL(k_draw_partition, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, base, ctx->d_jump_hi,
-					   ctx->d_jump_lo, n_chunks, (uint32_t)ctx->K, magic, l - 1, (uint32_t *)d_span.p);
+					   ctx->d_jump_lo, n_chunks, (uint32_t)ctx->K, magic, shift, (uint32_t *)d_span.p);
 		}
 	} else {
 		HIPCHK(d_span.alloc(16));	/* no copy draws: never read */
@@ -1826,17 +2257,54 @@ int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const
 	rng_window base;
 	size_t n_chunks, n_blocks;
 	if ((rc = rng_stream_setup(ctx, window, 2 * n_copies, &base, &n_chunks, &n_blocks))) return rc;
-	const size_t nq = eta_constrained ? (size_t)K : (size_t)I * K, np = (size_t)K * ctx->T;
+	const size_t n_qrows = eta_constrained ? 1 : (size_t)I, nq = n_qrows * K, np = (size_t)K * ctx->T;
+	const int fast = K <= SIM_QW && ctx->max_M <= SIM_PW;
+	const size_t ncq = n_qrows * (fast ? SIM_QW : K), ncp = fast ? (size_t)K * L * SIM_PW : np;
 	scoped_dev<double> d_q, d_p;
+	scoped_dev<uint32_t> d_cq, d_cp;
 	HIPCHK(d_q.alloc(nq));
 	HIPCHK(d_p.alloc(np));
-	if ((rc = stream_buffer(ctx))) return rc;	/* n_chunks * RNG_CHUNK / 2 <= its size */
-	uint8_t *d_raw = ctx->d_draw;
+	HIPCHK(d_cq.alloc(ncq));
+	HIPCHK(d_cp.alloc(ncp));
 	HIPCHK(hipMemcpyAsync(d_q, q, nq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(d_p, p, np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-	hipLaunchKernelGGL(k_simulate_admixture, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, base, ctx->d_jump_hi,
-			   ctx->d_jump_lo, n_chunks, n_copies, L, ploidy, K, ctx->T, ctx->d_toff, d_q.p, eta_constrained ? 0 : K, d_p.p,
-			   (uint32_t *)d_raw);
+	{
+		const size_t n = n_qrows > (size_t)K * L ? n_qrows : (size_t)K * L;
+		hipLaunchKernelGGL(k_walk_tables, dim3(nblk(n)), dim3(256), 0, ctx->stream, (int)n_qrows, K, L, ctx->T, ctx->d_toff, d_q.p, d_p.p,
+				   fast, d_cq.p, d_cp.p);
+	}
+	if (fast && ploidy <= 8 && !getenv("MCHIP_SIM_NO_TILE")) {
+		/* tile: as many loci as keep the staged thresholds near 16 KiB (three workgroups per compute unit), a multiple of 8 */
+		int tile = (16384 / (K * 12)) & ~7;
+		if (tile > 512) tile = 512;
+		if (tile > ((L + 7) & ~7)) tile = (L + 7) & ~7;
+		if ((rc = lattice_tables(ctx, 0, 2ull * (uint64_t)L * ploidy, (unsigned)I, 2ull * (uint64_t)tile * ploidy, (unsigned)((L + tile - 1) / tile))))
+			return rc;
+		switch (ploidy) {
+		case 1: launch_simulate_tile<1>(ctx, base, K, tile, d_cq.p, eta_constrained ? 0 : 1, d_cp.p); break;
+		case 2: launch_simulate_tile<2>(ctx, base, K, tile, d_cq.p, eta_constrained ? 0 : 1, d_cp.p); break;
+		case 3: launch_simulate_tile<3>(ctx, base, K, tile, d_cq.p, eta_constrained ? 0 : 1, d_cp.p); break;
+		case 4: launch_simulate_tile<4>(ctx, base, K, tile, d_cq.p, eta_constrained ? 0 : 1, d_cp.p); break;
+		case 5: launch_simulate_tile<5>(ctx, base, K, tile, d_cq.p, eta_constrained ? 0 : 1, d_cp.p); break;
+		case 6: launch_simulate_tile<6>(ctx, base, K, tile, d_cq.p, eta_constrained ? 0 : 1, d_cp.p); break;
+		case 7: launch_simulate_tile<7>(ctx, base, K, tile, d_cq.p, eta_constrained ? 0 : 1, d_cp.p); break;
+		default: launch_simulate_tile<8>(ctx, base, K, tile, d_cq.p, eta_constrained ? 0 : 1, d_cp.p); break;
+		}
+		HIPCHK(hipGetLastError());
+		rc = install_layouts(ctx, 0);
+		(void)hipStreamSynchronize(ctx->stream);	/* the temporaries go out of scope */
+		return rc;
+	}
+	if ((rc = stream_buffer(ctx))) return rc;	/* n_chunks * RNG_CHUNK / 2 <= its size */
+	uint8_t *d_raw = ctx->d_draw;
+	if (fast)
+		hipLaunchKernelGGL(k_simulate_admixture<true>, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, base, ctx->d_jump_hi,
+				   ctx->d_jump_lo, n_chunks, I, L, ploidy, K, ctx->T, ctx->d_toff, d_cq.p, eta_constrained ? 0 : 1, d_cp.p,
+				   (uint32_t *)d_raw);
+	else
+		hipLaunchKernelGGL(k_simulate_admixture<false>, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, base, ctx->d_jump_hi,
+				   ctx->d_jump_lo, n_chunks, I, L, ploidy, K, ctx->T, ctx->d_toff, d_cq.p, eta_constrained ? 0 : 1, d_cp.p,
+				   (uint32_t *)d_raw);
 	HIPCHK(hipGetLastError());
 	rc = install_raw(ctx, d_raw);
 	(void)hipStreamSynchronize(ctx->stream);	/* the temporaries go out of scope */

@@ -189,18 +189,19 @@ def test_random_kernel_variants_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, 
 
 def sim_cases(n, seed):
     rs = np.random.default_rng(seed)
-    return [(int(rs.integers(5, 300)), int(rs.integers(5, 700)), int(rs.choice([1, 2, 2, 3, 4, 6])), int(rs.choice([1, 2, 3, 5, 8, 13, 33, 64])),
-             int(rs.integers(0, 2)), int(rs.integers(0, 3000)), int(rs.integers(1, 1 << 30))) for _ in range(n)]
+    return [(int(rs.integers(5, 600)), int(rs.integers(5, 700)), int(rs.choice([1, 2, 2, 3, 4, 4, 5, 6, 8, 9])), int(rs.choice([1, 2, 3, 5, 7, 8, 9, 13, 33, 64])),
+             int(rs.choice([2, 3, 4, 4, 5, 9])), int(rs.integers(0, 2)), int(rs.integers(0, 3000)), int(rs.integers(1, 1 << 30))) for _ in range(n)]
 
 
-@pytest.mark.parametrize("I,L,ploidy,K,constrained,skip,seed", sim_cases(12 * SCALE, 3 + SEED_SHIFT))
-def test_random_bootstrap_data_sets_device_vs_host(ctx, I, L, ploidy, K, constrained, skip, seed):
+@pytest.mark.parametrize("I,L,ploidy,K,maxal,constrained,skip,seed", sim_cases(16 * SCALE, 3 + SEED_SHIFT))
+def test_random_bootstrap_data_sets_device_vs_host(ctx, I, L, ploidy, K, maxal, constrained, skip, seed):
     """parametric_bootstrap_admixture (bootstrap.c:84-124) generated on the device from the stream's window against the host
     generator (pinned to the reference's own data sets by tests/test_bootstrap_cpu.py), byte for byte, for random shapes,
-    ploidies, K up to 64, both eta forms and stream offsets."""
+    ploidies, K up to 64, both eta forms and stream offsets; at most 4 alleles per locus with K <= 8 and ploidy <= 8 takes the
+    tiled generator (thresholds in LDS, written straight into the device layouts), everything else the chunked one."""
     import ctypes as C
     from multiclust_amd import host
-    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=5, seed=seed % 9973, missing=0.02)
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=seed % 9973, missing=0.02)
     lb = ob.lib.mco_lower_bound(1e-8, I, ploidy)
     q, p = random_params(I, ua, K, seed=seed % 7919, lower_bound=lb)
     q[::3, 0] = lb
