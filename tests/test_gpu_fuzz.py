@@ -96,17 +96,20 @@ def test_random_shapes_mixture_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, s
 
 def draw_cases(n, seed):
     rs = np.random.default_rng(seed)
-    return [(int(rs.integers(3, 400)), int(rs.integers(3, 900)), int(rs.integers(1, 5)), int(rs.integers(1, 65)),
+    return [(int(rs.integers(3, 700)), int(rs.integers(3, 900)), int(rs.choice([1, 2, 2, 3, 4, 4, 5, 6, 7, 8, 9])), int(rs.integers(1, 65)),
+             int(rs.choice([2, 3, 4, 7, 12])), float(rs.choice([0.0, 0.0, 0.05])), int(rs.integers(0, 2)),
              int(rs.integers(0, 5000)), int(rs.integers(1, 1 << 31))) for _ in range(n)]
 
 
-@pytest.mark.parametrize("I,L,ploidy,K,skip,seed", draw_cases(30 * SCALE, 11 + SEED_SHIFT))
-def test_random_device_draws_vs_host_stream(ctx, I, L, ploidy, K, skip, seed):
+@pytest.mark.parametrize("I,L,ploidy,K,maxal,missing,constrained,skip,seed", draw_cases(40 * SCALE, 11 + SEED_SHIFT))
+def test_random_device_draws_vs_host_stream(ctx, I, L, ploidy, K, maxal, missing, constrained, skip, seed):
     """random_allele_partition drawn on the device = drawn from the oracle's glibc stream on the host, for random sizes,
-    seeds, stream offsets and every K up to 64 (the multiply-shift remainder)."""
-    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=3, seed=seed % 1000, missing=0.0)
+    seeds, stream offsets and every K up to 64 (the multiply-shift remainder).  The device form draws and counts tile by tile
+    without storing an assignment (ploidy <= 8); the uploaded partition goes through the layout and counting kernels: two
+    independent routes to the same counts, with missing copies, repeated (allele, cluster) pairs and both eta forms."""
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=seed % 1000, missing=missing)
     ctx.set_genotypes(ua, geno)
-    ctx.set_model(K, lower_bound=1e-8)
+    ctx.set_model(K, lower_bound=1e-8, eta_constrained=constrained)
     window, rng = ob.glibc_window(seed, skip)
     assign = ob.rand_mod(rng, I * L * ploidy, K)
     ctx.mstep_from_partition(assign, 0)
