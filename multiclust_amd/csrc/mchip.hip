@@ -808,13 +808,28 @@ __global__ void k_transpose_tk_to_kt(const double *__restrict__ src, double *__r
 	dst[idx] = src[c * K + k];
 }
 
+/* acc + in[first] + in[first + stride] + ... (count terms, added in that order): the loads of eight terms are issued
+ * together, the additions keep their order, so the result is the plain loop's to the last bit */
+__device__ __forceinline__ double ordered_sum(double acc, const double *__restrict__ in, size_t first, size_t stride, int count)
+{
+	int x = 0;
+	for (; x + 8 <= count; x += 8) {
+		double v[8];
+#pragma unroll
+		for (int y = 0; y < 8; y++) v[y] = in[first + (size_t)(x + y) * stride];
+#pragma unroll
+		for (int y = 0; y < 8; y++) acc += v[y];
+	}
+	for (; x < count; x++) acc += in[first + (size_t)x * stride];
+	return acc;
+}
+
 /* deterministic sum of n doubles (fixed strided order, then a fixed tree): one block */
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_sum(const double *__restrict__ in, int n, double *out, const int *stop = nullptr)
 {
 	__shared__ double red[MCHIP_BLOCK];
 	if (stop && *stop) return;
-	double s = 0.0;
-	for (int x = threadIdx.x; x < n; x += MCHIP_BLOCK) s += in[x];
+	const double s = (int)threadIdx.x < n ? ordered_sum(0.0, in, threadIdx.x, MCHIP_BLOCK, (n - (int)threadIdx.x + MCHIP_BLOCK - 1) / MCHIP_BLOCK) : 0.0;
 	red[threadIdx.x] = s;
 	__syncthreads();
 	for (int w = MCHIP_BLOCK / 2; w > 0; w >>= 1) {
@@ -835,8 +850,7 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_sum_slabs(const double *__restr
 	const int e_local = threadIdx.x & 31, s = threadIdx.x >> 5;
 	const size_t e = (size_t)blockIdx.x * 32 + e_local;
 	double acc = 0.0;
-	if (e < n)
-		for (int j = s; j < n_slabs; j += 8) acc += slabs[(size_t)j * n + e];
+	if (e < n && s < n_slabs) acc = ordered_sum(0.0, slabs, (size_t)s * n + e, 8 * n, (n_slabs - s + 7) / 8);
 	part[s][e_local] = acc;
 	__syncthreads();
 	if (s == 0 && e < n) {
@@ -888,8 +902,7 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_p(int L, int K, int T,
 	double temp = 0.0;
 	for (int m = 0; m < M; m++) {
 		const size_t e = (size_t)(c0 + m) * K + k;
-		double s = 0.0;
-		for (int ch = 0; ch < n_ichunks; ch++) s += Apart[(size_t)ch * T * K + e];
+		double s = ordered_sum(0.0, Apart, e, (size_t)T * K, n_ichunks);
 		if (weighted) s *= Pfrom[e];
 		s += add_lb;		/* mixture M step starts every sum at p_lower_bound (em_alg.c:972); 0 otherwise */
 		Pto[e] = s;
@@ -954,8 +967,7 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_stop_check(mchip_run_state *s, 
 	__shared__ double red[MCHIP_BLOCK];
 	if (s->stopped) return;		/* uniform */
 	if (part) {
-		double acc = 0.0;
-		for (int x = threadIdx.x; x < n; x += MCHIP_BLOCK) acc += part[x];
+		const double acc = (int)threadIdx.x < n ? ordered_sum(0.0, part, threadIdx.x, MCHIP_BLOCK, (n - (int)threadIdx.x + MCHIP_BLOCK - 1) / MCHIP_BLOCK) : 0.0;
 		red[threadIdx.x] = acc;
 		__syncthreads();
 		for (int w = MCHIP_BLOCK / 2; w > 0; w >>= 1) {
@@ -1583,10 +1595,14 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	 * per CU cost 6.9 ms per EM step, 64 per CU 5.4 ms (profiles/r01_geometry_sweep.txt).  More chunks mean
 	 * more partial-sum slabs (Apart/Spart are written and re-read once per step), so the chunk count is capped
 	 * where the slab bytes reach ~30 % of the genotype bytes the pass streams (config 2: 0.188 -> 0.179 ms per step against 15 %;
-	 * config 3 reaches its 64 workgroups per CU before either cap).  Chunk sizes are multiples of 8. */
-	int per_cu = 64;
-	if (const char *e = getenv("MCHIP_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;	/* tuning knob */
-	const int target = per_cu * ctx->n_cu;
+	 * config 3 reaches its 64 workgroups per CU before either cap).  The column pass stops at 15 % once the grid fills the
+	 * device twice over: its slabs are K*T doubles each and k_finalize_p reads them all (config 5: 28 -> 15 slabs, 1.61 ->
+	 * 1.56 ms per step; scripts/diag/geom.sh).  Chunk sizes are multiples of 8. */
+	int per_cu_col = 64, per_cu_ind = 64;
+	if (const char *e = getenv("MCHIP_BLOCKS_PER_CU")) per_cu_col = per_cu_ind = atoi(e) > 0 ? atoi(e) : 64;	/* tuning knobs */
+	if (const char *e = getenv("MCHIP_BLOCKS_PER_CU_COL")) per_cu_col = atoi(e) > 0 ? atoi(e) : per_cu_col;
+	if (const char *e = getenv("MCHIP_BLOCKS_PER_CU_IND")) per_cu_ind = atoi(e) > 0 ? atoi(e) : per_cu_ind;
+	int target = per_cu_col * ctx->n_cu;
 	const int col_tiles = (ctx->T + MCHIP_BLOCK - 1) / MCHIP_BLOCK;
 	const int iblocks = (ctx->I + 7) / 8, lblocks = (ctx->L + 7) / 8;
 	double slab_frac = 0.3;
@@ -1595,6 +1611,12 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	int min_ichunk = (int)ceil(8.0 * K * ctx->T / (slab_frac * ctx->L * ctx->ploidy));
 	int want = (target + col_tiles - 1) / col_tiles;
 	int cap = ctx->I / (min_ichunk > 0 ? min_ichunk : 1);
+	{
+		const int cap_lo = cap / 2;						/* half the slab budget */
+		const int fill = (2 * 8 * ctx->n_cu + col_tiles - 1) / col_tiles;	/* two rounds of 8 resident workgroups per CU */
+		const int soft = cap_lo > (fill < cap ? fill : cap) ? cap_lo : (fill < cap ? fill : cap);
+		if (!getenv("MCHIP_BLOCKS_PER_CU") && !getenv("MCHIP_BLOCKS_PER_CU_COL") && !getenv("MCHIP_SLAB_FRAC") && want > soft) want = soft;
+	}
 	if (want > cap) want = cap;
 	if (want < 1) want = 1;
 	if (want > iblocks) want = iblocks;
@@ -1607,6 +1629,7 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	/* individual pass: slab bytes per chunk 8*K*I, genotype bytes per chunk lchunk*I*ploidy */
 	const int ind_tiles = (ctx->I + MCHIP_QBLOCK - 1) / MCHIP_QBLOCK;
 	int min_lchunk = (int)ceil(8.0 * K / (slab_frac * ctx->ploidy));
+	target = per_cu_ind * ctx->n_cu;
 	want = (target + ind_tiles - 1) / ind_tiles;
 	cap = ctx->L / (min_lchunk > 0 ? min_lchunk : 1);
 	if (want > cap) want = cap;
