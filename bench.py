@@ -271,7 +271,7 @@ def roofline_object(ctx, w, T, K, it_per_s_per_gpu, workload, nnz):
     kl = (C.c_int * hip.PROF_KINDS)()
     hlib.mchip_profile_end(ctx, C.byref(total_ms), km, kl)
     B = algorithmic_bytes(w, T, K)
-    names = ["column_pass", "individual_pass", "loglik_pass"]
+    names = ["column_pass", "individual_pass", "loglik_pass", "individual_dual_pass"]
     avg = [km[x] / kl[x] if kl[x] else 0.0 for x in range(hip.PROF_KINDS)]
     dom = max(range(2), key=lambda x: avg[x])
     ach = B[names[dom]] / (avg[dom] * 1e-3) / 1e9 if avg[dom] else 0.0

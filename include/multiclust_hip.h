@@ -244,10 +244,12 @@ int mchip_profile_begin(mchip_context *ctx);
 /* total_ms: begin..end on the stream.  kernel_ms[MCHIP_PROF_KINDS] / launches[MCHIP_PROF_KINDS]: summed
  * durations and launch counts of the streaming passes over the genotype matrix, each launch bracketed
  * by its own event pair: [0] column pass of an EM step (N-side sums + logL), [1] individual pass
- * (S-side sums), [2] stand-alone log-likelihood pass.  Launches that returned at once (batched runs: after the stopping
+ * (S-side sums), [2] stand-alone log-likelihood pass, [3] dual individual pass of a batched accelerated cycle (the S-side
+ * sums of the extrapolated point and the log likelihood of the second EM iterate in one pass; then [2] has no launches).
+ * Launches that returned at once (batched runs: after the stopping
  * rule fired, or the S-side pass whose sums were already in place) took under 5 % of the kind's longest launch and are
  * left out of both figures. */
-#define MCHIP_PROF_KINDS 3
+#define MCHIP_PROF_KINDS 4
 int mchip_profile_end(mchip_context *ctx, double *total_ms, double *kernel_ms, int *launches);
 /* device properties the bench reports (name, CU count, memory) */
 int mchip_device_info(mchip_context *ctx, char *name, int name_len, int *compute_units, double *hbm_bytes);

@@ -82,6 +82,7 @@ struct mchip_context {
 	int ichunk, n_ichunks, lchunk, n_lchunks, n_llpart, n_ll_col, n_ll_ind, flush_blocks, safe_rcp, sparse;
 	double *d_ssum;			/* [I][K] chunk-summed S-side sums */
 	double *d_Apart, *d_Spart, *d_llpart, *d_scalars;	/* d_scalars: [0]=logL, [1..3]=dots, [4..]=eta sums */
+	double *d_llpart2;		/* partial log likelihoods of the second parameter set of a dual individual pass */
 	double *d_redpart;		/* block partials of the dot products / column sums */
 	uint8_t *d_flags;		/* michelot "fixed" flags for loci with more than 64 alleles */
 	double *h_pinned;		/* 64 doubles */
@@ -1154,7 +1155,7 @@ static void free_model(mchip_context *ctx)
 	drop_graphs(ctx);
 	for (int s = 0; s < 3; s++) { dfree(ctx->d_p[s]); dfree(ctx->d_q[s]); }
 	for (int s = 0; s < MCHIP_MAX_SECANTS; s++) { dfree(ctx->d_up[s]); dfree(ctx->d_vp[s]); dfree(ctx->d_uq[s]); dfree(ctx->d_vq[s]); }
-	dfree(ctx->d_sik); dfree(ctx->d_stage); dfree(ctx->d_logp); dfree(ctx->d_ssum); dfree(ctx->d_Apart); dfree(ctx->d_Spart); dfree(ctx->d_llpart);
+	dfree(ctx->d_sik); dfree(ctx->d_stage); dfree(ctx->d_logp); dfree(ctx->d_ssum); dfree(ctx->d_Apart); dfree(ctx->d_Spart); dfree(ctx->d_llpart); dfree(ctx->d_llpart2);
 	dfree(ctx->d_redpart); dfree(ctx->d_flags);
 	ctx->K = 0;
 	ctx->parked_K = 0;
@@ -1648,6 +1649,7 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	HIPCHK(hipMalloc((void **)&ctx->d_Apart, (size_t)ctx->n_ichunks * KT * sizeof(double)));
 	HIPCHK(hipMalloc((void **)&ctx->d_Spart, (size_t)ctx->n_lchunks * ctx->I * K * sizeof(double)));
 	HIPCHK(hipMalloc((void **)&ctx->d_llpart, (size_t)ctx->n_llpart * sizeof(double)));
+	HIPCHK(hipMalloc((void **)&ctx->d_llpart2, (size_t)ctx->n_llpart * sizeof(double)));
 	HIPCHK(hipMalloc((void **)&ctx->d_redpart, (size_t)3 * 1024 * sizeof(double)));
 	if (ctx->max_M > 64) {
 		HIPCHK(hipMalloc((void **)&ctx->d_flags, KT));
@@ -2460,10 +2462,17 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 	hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_run, ctx->d_scalars, ctx->d_llpart, ctx->ll_parts);
 	hipLaunchKernelGGL(k_diff, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[C], ctx->d_p[B], ctx->d_vp[0], KT, stop);
 	hipLaunchKernelGGL(k_diff, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[C], ctx->d_q[B], ctx->d_vq[0], nq, stop);
-	/* emll = log_likelihood(findex = C) -> d_scalars[1] (accel_em.c:53) */
+	/* emll = log_likelihood(findex = C) -> d_scalars[1] (accel_em.c:53).  Admixture model: where the dual individual pass
+	 * exists, emll is taken below, by the pass that visits the extrapolated point (same kernel arithmetic, same bits) */
+	mchip_pass_args dual = pass_args(ctx, B);
+	dual.stop = stop;
+	dual.P2 = ctx->d_p[C];
+	dual.Q2 = ctx->d_q[C];
+	dual.llpart2 = ctx->d_llpart2;
+	const bool use_dual = ctx->admixture && !getenv("MCHIP_NO_DUAL") && ctx->kt->dual_available(dual);
 	if (!ctx->admixture) {
 		if ((rc = run_mixture(ctx, C, C, 0, 1, stop, 1))) return rc;	/* logL_mixture */
-	} else {
+	} else if (!use_dual) {
 		mchip_pass_args a = pass_args(ctx, C);
 		a.stop = stop;
 		prof_mark(ctx, MCHIP_KERN_LOGLIK, true);
@@ -2482,11 +2491,18 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 	if (!ctx->admixture) {
 		if ((rc = run_mixture(ctx, B, B, 0, 1, stop, 2))) return rc;	/* nothing of this pass serves the next E step */
 	} else {
-		mchip_pass_args a = pass_args(ctx, B);
-		a.stop = stop;
-		prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
-		ctx->kt->accum_q(a, ctx->stream);
-		prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
+		if (use_dual) {
+			prof_mark(ctx, MCHIP_KERN_DUAL, true);
+			ctx->kt->accum_q_dual(dual, ctx->stream);
+			prof_mark(ctx, MCHIP_KERN_DUAL, false);
+			hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart2, ctx->n_ll_ind, ctx->d_scalars + 1, stop);
+		} else {
+			mchip_pass_args a = pass_args(ctx, B);
+			a.stop = stop;
+			prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
+			ctx->kt->accum_q(a, ctx->stream);
+			prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
+		}
 		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_ll_ind, ctx->d_scalars + 2, stop);
 	}
 	/* accept iff ll > emll; the outcome goes back to slot A */
@@ -2583,8 +2599,8 @@ int mchip_profile_end(mchip_context *ctx, double *total_ms, double *kernel_ms, i
 	float ms = 0;
 	HIPCHK(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
 	if (total_ms) *total_ms = ms;
-	double km[MCHIP_KERN_COUNT] = {0, 0, 0}, longest[MCHIP_KERN_COUNT] = {0, 0, 0};
-	int kl[MCHIP_KERN_COUNT] = {0, 0, 0};
+	double km[MCHIP_KERN_COUNT] = {0}, longest[MCHIP_KERN_COUNT] = {0};
+	int kl[MCHIP_KERN_COUNT] = {0};
 	std::vector<float> each(ctx->ev_kind.size(), 0.0f);
 	for (size_t p = 0; 2 * p + 1 < ctx->ev_used && p < ctx->ev_kind.size(); p++) {
 		HIPCHK(hipEventElapsedTime(&each[p], ctx->ev_pool[2 * p], ctx->ev_pool[2 * p + 1]));

@@ -27,7 +27,7 @@
 #define MCHIP_QBLOCK 128	/* individuals per workgroup of the individual-side kernels (lane = individual) */
 #endif	/* sparse individual pass is used when no locus has more alleles than this */
 
-enum { MCHIP_KERN_ACCUM_P = 0, MCHIP_KERN_ACCUM_Q = 1, MCHIP_KERN_LOGLIK = 2, MCHIP_KERN_COUNT = 3 };
+enum { MCHIP_KERN_ACCUM_P = 0, MCHIP_KERN_ACCUM_Q = 1, MCHIP_KERN_LOGLIK = 2, MCHIP_KERN_DUAL = 3, MCHIP_KERN_COUNT = 4 };
 
 /* arguments of the two streaming passes over the genotype matrix */
 struct mchip_pass_args {
@@ -59,6 +59,9 @@ struct mchip_pass_args {
 	/* batched accelerated runs: when non-null and *skip_ind != 0 the S-side pass returns at once, because the pass that
 	 * took the log likelihood of these very parameters (the accepted extrapolation) already left its sums in Spart */
 	const int *skip_ind;
+	/* dual individual pass: a second parameter set whose log likelihood the same pass takes */
+	const double *P2, *Q2;
+	double *llpart2;
 	/* hard-partition first M step */
 	const uint8_t *asA, *asS;	/* assignment bytes in the gtA / gtS layouts */
 	int part_counts;		/* 0: d_iklm = 1 per (allele, cluster) pair, missing copies skipped (random_allele_partition);
@@ -82,6 +85,9 @@ struct mchip_ktable {
 	void (*mix_finalize)(int I, int n_lchunks, const double *Vpart, const double *eta, double *vik, double *llpart, int mode,
 			     const int *stop, hipStream_t s);
 	void (*mix_column)(const mchip_pass_args &a, hipStream_t s);	/* a.Q = vik; Apart = sum_i vik n */
+	/* individual pass of (a.Q, a.P) that also takes log L of (a.Q2, a.P2) into a.llpart2, where dual_available() says so */
+	int (*dual_available)(const mchip_pass_args &a);
+	void (*accum_q_dual)(const mchip_pass_args &a, hipStream_t s);
 };
 
 const mchip_ktable *mchip_get_ktable(int K);

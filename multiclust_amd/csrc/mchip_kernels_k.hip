@@ -410,28 +410,37 @@ __device__ __forceinline__ void rescale(double &prod, int &ex)
 	}
 }
 
-template <int PL, bool ACCUM, bool SAFE, bool NOMISS>
+/* DUAL (with ACCUM, diploid, !SAFE): the same pass also takes the log likelihood of a second parameter set
+ * (a.Q2, a.P2 -> a.llpart2), with the arithmetic of the ACCUM = false instance, lane for lane: an accelerated cycle needs
+ * log L of its second EM iterate and the E step of the extrapolated point back to back (accel_em.c:53,544); the first is
+ * bound by the LDS gather, the second by FP64 issue, and one kernel overlaps some of the two: 2.78-2.88 ms against 1.84 + 1.15
+ * at config 3 (scripts/diag/dual.sh).  Tetraploid data loses (1.53 against 0.90 + 0.55 ms at config 5's shape: 170 registers,
+ * three waves per SIMD): not instantiated */
+template <int PL, bool ACCUM, bool SAFE, bool NOMISS, bool DUAL = false>
 __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_sparse(mchip_pass_args a)
 {
+	static_assert(!DUAL || (ACCUM && !SAFE && PL == 2), "dual pass: ACCUM, shared reciprocals, diploid");
 	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
-	if (ACCUM && a.skip_ind && *a.skip_ind) return;	/* sums + logL partials of these parameters are already there */
-	extern __shared__ __attribute__((aligned(16))) double lds[];	/* [2][tile_cols][KP] then [QBLOCK] reduction scratch */
-	double *red = lds + 2 * (size_t)a.tile_cols * KP;
+	if (ACCUM && !DUAL && a.skip_ind && *a.skip_ind) return;	/* sums + logL partials of these parameters are already there */
+	extern __shared__ __attribute__((aligned(16))) double lds[];	/* [2][tile_cols][KP] (DUAL: twice) then [QBLOCK] reduction scratch */
+	double *lds2 = lds + 2 * (size_t)a.tile_cols * KP;
+	double *red = lds + (DUAL ? 4 : 2) * (size_t)a.tile_cols * KP;
 	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
 	const bool active = i_raw < a.I;
 	const int i = active ? i_raw : a.I - 1;
 	const int pl = PL ? PL : a.ploidy;
-	double q[K], acc[K];
+	double q[K], acc[K], q2[DUAL ? K : 1];
 #pragma unroll
 	for (int k = 0; k < K; k++) {
 		q[k] = a.Q[(size_t)i * a.qstride + k];
 		acc[k] = 0.0;
+		if constexpr (DUAL) q2[k] = a.Q2[(size_t)i * a.qstride + k];
 	}
 	const int l0 = blockIdx.y * a.lchunk;
 	const int l1 = min(a.L, l0 + a.lchunk);
 	const int lb0 = l0 >> 3, lb_end = (l1 + 7) >> 3;
-	double prod = 1.0;
-	int blk = 0, ex = 0;
+	double prod = 1.0, prod2 = 1.0;
+	int blk = 0, ex = 0, ex2 = 0;
 	constexpr int STAGE = 2;
 	const bool staged = a.tile_cols * K <= STAGE * QBLOCK;	/* wave-uniform */
 
@@ -439,8 +448,10 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 	{
 		const int c_lo = a.toff[lb0 * 8], c_hi = a.toff[min(lb0 * 8 + 8, a.L)];
 		const int nel = (c_hi - c_lo) * K;
-		for (int x = threadIdx.x; x < nel; x += QBLOCK)
+		for (int x = threadIdx.x; x < nel; x += QBLOCK) {
 			lds[(x / K) * KP + (x % K)] = a.P[(size_t)c_lo * K + x];
+			if (DUAL) lds2[(x / K) * KP + (x % K)] = a.P2[(size_t)c_lo * K + x];
+		}
 	}
 	geno_group<PL> g, gn;
 	g.load(a.gtS, (size_t)lb0 * a.I + i, pl);
@@ -448,25 +459,32 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 	for (int lb = lb0; lb < lb_end; lb++) {
 		const int buf = (lb - lb0) & 1;
 		const double *tile = lds + (size_t)buf * a.tile_cols * KP;
+		const double *tile2 = lds2 + (size_t)buf * a.tile_cols * KP;
 		const int c_lo = a.toff[lb * 8];
 		/* prefetch the next tile and the next genotype group.  Tiles of up to STAGE * QBLOCK doubles (every data set with
 		 * <= 4 alleles per locus at K <= 8) wait in registers while this block is computed and go to the other LDS buffer
 		 * after it, so no s_waitcnt for them sits in front of the arithmetic; larger tiles are copied through at once */
-		double stage[STAGE];
+		double stage[STAGE], stage2[DUAL ? STAGE : 1];
 		int nel_next = 0;
 		double *dst = lds + (size_t)(buf ^ 1) * a.tile_cols * KP;
+		double *dst2 = lds2 + (size_t)(buf ^ 1) * a.tile_cols * KP;
 		if (lb + 1 < lb_end) {
 			const int n_lo = a.toff[(lb + 1) * 8], n_hi = a.toff[min((lb + 1) * 8 + 8, a.L)];
 			nel_next = (n_hi - n_lo) * K;
 			const double *src = a.P + (size_t)n_lo * K;
+			const double *src2 = DUAL ? a.P2 + (size_t)n_lo * K : nullptr;
 			if (staged) {
 #pragma unroll
 				for (int s2 = 0; s2 < STAGE; s2++) {
 					const int x = threadIdx.x + s2 * QBLOCK;
 					stage[s2] = src[min(x, nel_next - 1)];
+					if constexpr (DUAL) stage2[s2] = src2[min(x, nel_next - 1)];
 				}
 			} else {
-				for (int x = threadIdx.x; x < nel_next; x += QBLOCK) dst[(x / K) * KP + (x % K)] = src[x];
+				for (int x = threadIdx.x; x < nel_next; x += QBLOCK) {
+					dst[(x / K) * KP + (x % K)] = src[x];
+					if (DUAL) dst2[(x / K) * KP + (x % K)] = src2[x];
+				}
 			}
 		}
 		gn.load(a.gtS, (size_t)min(lb + 1, lb_end - 1) * a.I + i, pl);
@@ -483,12 +501,14 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 				/* all copies of the locus first (t), then one shared reciprocal for each pair of copies */
 				double pc[PL ? PL : 1][KP], t[PL ? PL : 1];
 				bool miss[PL ? PL : 1];
+				unsigned row[PL ? PL : 1];
 #pragma unroll
 				for (int b = 0; b < PL; b++) {
 					const unsigned mraw = g.copy(j, b, pl);
 					/* NOMISS: the data set has no missing copy: no selects (idle lanes duplicate individual I-1) */
 					miss[b] = NOMISS ? false : ((mraw == MCHIP_MISSING) || !active);
 					const unsigned mm = miss[b] ? 0u : mraw;
+					row[b] = (unsigned)base + mm;
 					/* 16-byte LDS reads (ds_read_b128): twice the bytes per LDS cycle of ds_read2_b64 */
 					const double2 *pr = reinterpret_cast<const double2 *>(tile + (size_t)(base + (int)mm) * KP);
 #pragma unroll
@@ -531,6 +551,27 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 					} else {
 						prod *= pp;
 					}
+					if constexpr (DUAL) {	/* the second set's t of the same two copies: gather, dot product, into its own log-product
+								 * (requesting these rows ahead of the accumulation above costs 30 more registers and a wave
+								 * of occupancy: measured slower) */
+						double t2[2];
+#pragma unroll
+						for (int bb = 0; bb < 2; bb++) {
+							const double2 *pr = reinterpret_cast<const double2 *>(tile2 + (size_t)row[b + bb] * KP);
+							double pc2[KP];
+#pragma unroll
+							for (int k = 0; k < KP / 2; k++) {
+								const double2 v = pr[k];
+								pc2[2 * k] = v.x;
+								pc2[2 * k + 1] = v.y;
+							}
+							t2[bb] = q2[0] * pc2[0];
+#pragma unroll
+							for (int k = 1; k < K; k++) t2[bb] = __builtin_fma(q2[k], pc2[k], t2[bb]);
+							if (!NOMISS) t2[bb] = miss[b + bb] ? 1.0 : t2[bb];
+						}
+						prod2 *= t2[0] * t2[1];
+					}
 				}
 			} else {
 				for (int bb = 0; bb < pl; bb++) {	/* any other ploidy: one copy at a time */
@@ -561,6 +602,7 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 				if (++blk >= a.flush_blocks) {
 					blk = 0;
 					rescale(prod, ex);
+					if (DUAL) rescale(prod2, ex2);
 				}
 			}
 		};
@@ -578,6 +620,7 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 			for (int s2 = 0; s2 < STAGE; s2++) {
 				const int x = threadIdx.x + s2 * QBLOCK;
 				if (x < nel_next) dst[(x / K) * KP + (x % K)] = stage[s2];
+				if constexpr (DUAL) { if (x < nel_next) dst2[(x / K) * KP + (x % K)] = stage2[s2]; }
 			}
 		}
 		g = gn;
@@ -591,6 +634,12 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 	}
 	const double tot = block_sum<QBLOCK>(active ? ll : 0.0, red);
 	if (threadIdx.x == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+	if (DUAL) {
+		const double ll2 = (double)ex2 * 0.693147180559945309417 + log(prod2);
+		__syncthreads();	/* red[] is read by thread 0 above */
+		const double tot2 = block_sum<QBLOCK>(active ? ll2 : 0.0, red);
+		if (threadIdx.x == 0) a.llpart2[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot2;
+	}
 }
 
 /* ---------------------------------------------------------------- individual pass, every locus biallelic (SNP data)
@@ -1035,6 +1084,23 @@ template <bool ACCUM> void launch_sparse(const mchip_pass_args &a, hipStream_t s
 	else hipLaunchKernelGGL((k_individual_sparse<0, ACCUM, true, false>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
 #undef MCHIP_SPARSE
 }
+/* the dual pass exists where both of its halves would run the sparse kernel with shared reciprocals (so that its results are
+ * theirs bit for bit) and the second set's registers still fit */
+inline size_t dual_lds_bytes(const mchip_pass_args &a) { return (4 * (size_t)a.tile_cols * KP + QBLOCK) * sizeof(double); }
+int dual_available(const mchip_pass_args &a)
+{
+	if (K > 12 || !a.sparse || a.flush_blocks < 1 || a.ploidy != 2) return 0;
+	if (a.biallelic && K >= 6) return 0;	/* launch_sparse takes k_individual_bial for one or both passes */
+	return dual_lds_bytes(a) <= 64 * 1024;
+}
+void launch_accum_q_dual(const mchip_pass_args &a, hipStream_t s)
+{
+	if constexpr (K <= 12) {
+		const size_t lds = dual_lds_bytes(a);
+		if (!a.has_missing) hipLaunchKernelGGL((k_individual_sparse<2, true, false, true, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
+		else hipLaunchKernelGGL((k_individual_sparse<2, true, false, false, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
+	}
+}
 void launch_loglik(const mchip_pass_args &a, hipStream_t s)
 {
 	if (a.sparse) { launch_sparse<false>(a, s); return; }
@@ -1103,7 +1169,7 @@ const mchip_ktable *MCHIP_CAT(mchip_ktable_get_, MCHIP_K)()
 {
 	static mchip_ktable t = {
 		launch_accum_p, launch_loglik, launch_accum_q, launch_part_p, launch_part_q, launch_finalize_q, launch_project_q,
-		launch_mix_gather, launch_mix_finalize, launch_mix_column,
+		launch_mix_gather, launch_mix_finalize, launch_mix_column, dual_available, launch_accum_q_dual,
 	};
 	return &t;
 }

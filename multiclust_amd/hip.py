@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-PROF_KINDS = 3
+PROF_KINDS = 4
 STATUS = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "ALLOC", 5: "STATE", 6: "UNSUPPORTED"}
 
 

@@ -339,3 +339,31 @@ def test_batched_accelerated_run_honours_the_iteration_cap():
                 os.environ["MC_NO_BATCH"] = old
     assert res[0][:4] == res[1][:4] and res[0][0] == 7 and res[0][1] == 1
     assert np.array_equal(res[0][4], res[1][4])
+
+
+@pytest.mark.parametrize("K,maxal,missing,scheme", [(2, 4, 0.0, 3), (5, 2, 0.0, 3), (8, 4, 0.0, 3), (8, 3, 0.04, 1), (12, 4, 0.02, 2),
+                                                     (6, 2, 0.0, 3), (13, 4, 0.0, 3), (8, 4, 0.0, 4)])
+def test_dual_individual_pass_equals_the_two_passes(K, maxal, missing, scheme, monkeypatch):
+    """A batched accelerated cycle of diploid data takes log L of the second EM iterate and the E step of the extrapolated point
+    in one pass over the genotypes (k_individual_sparse<.., DUAL>; K <= 12, not where the all-biallelic kernels apply: the
+    (6, 2) and K = 13 cases run the two passes either way).  Same arithmetic lane for lane: whole fits with it and with
+    MCHIP_NO_DUAL=1 (the two separate passes) end on the same bits, and both equal the cycle-by-cycle host loop."""
+    from multiclust_amd import host
+    from synth import make_dataset
+    ua, geno = make_dataset(300, 700, K, ploidy=2, max_alleles=maxal, seed=77 + K, missing=missing)
+    out = []
+    for env in ({}, {"MCHIP_NO_DUAL": "1"}, {"MC_NO_BATCH": "1"}):
+        for k in ("MCHIP_NO_DUAL", "MC_NO_BATCH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        fit = host.Fit(ua, geno, K, admixture=1, accel_scheme=scheme, verbosity=1, max_iter=24)
+        fit.initialize(4242)
+        fit.em()
+        m = fit.mod
+        assert m.fatal == 0
+        out.append((m.n_iter, m.converged, m.iter_stop, m.logL, fit.get_q(m.pindex), fit.get_p(m.pindex), fit.expected_counts()))
+        fit.close()
+    for other in out[1:]:
+        assert out[0][:4] == other[:4], (out[0][:4], other[:4])
+        assert np.array_equal(out[0][4], other[4]) and np.array_equal(out[0][5], other[5]) and np.array_equal(out[0][6], other[6])
