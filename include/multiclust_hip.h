@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCHIP_ABI_VERSION 1
+#define MCHIP_ABI_VERSION 2	/* 2: mchip_profile_end fills MCHIP_PROF_KINDS = 4 entries (was 3); entry points added since 1 only */
 #define MCHIP_MISSING 0xFF	/* genotype byte for a missing allele copy (reference MISSING = -9, multiclust.h:140) */
 #define MCHIP_MAX_K 64		/* clusters supported by the K-specialised kernels (cost ~ 2K+6 per cell up to K ~ 20; above
 				 * that the 2K-4K doubles a lane holds cost occupancy, above 32 they spill) */

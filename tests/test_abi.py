@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_device_count():
     lib = mc.load()
-    assert lib.mchip_abi_version() == 1
+    assert lib.mchip_abi_version() == 2
     n = C.c_int(-1)
     assert lib.mchip_device_count(C.byref(n)) == 0
     assert n.value >= 0
