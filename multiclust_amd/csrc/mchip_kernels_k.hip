@@ -425,6 +425,14 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 	extern __shared__ __attribute__((aligned(16))) double lds[];	/* [2][tile_cols][KP] (DUAL: twice) then [QBLOCK] reduction scratch */
 	double *lds2 = lds + 2 * (size_t)a.tile_cols * KP;
 	double *red = lds + (DUAL ? 4 : 2) * (size_t)a.tile_cols * KP;
+#ifdef MCHIP_EXP_SCATTER
+	/* EXPERIMENT (never in the product build; scripts/diag/scatter_exp.sh): what it would cost this pass to also form the
+	 * N-side sums by scattering q_ik * r into per-workgroup LDS accumulators [column of the tile][K] with hardware
+	 * ds_add_f64 -- the "(f)" alternative of DESIGN.md 4.3.  Only the atomics are issued (the accumulators are never flushed to
+	 * memory, which would cost more): a lower bound on that design's S-side pass. */
+	double *nacc = red + QBLOCK;
+	for (int x = threadIdx.x; x < a.tile_cols * KP; x += QBLOCK) nacc[x] = 0.0;
+#endif
 	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
 	const bool active = i_raw < a.I;
 	const int i = active ? i_raw : a.I - 1;
@@ -542,6 +550,12 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b][k], r0, acc[k]);
 #pragma unroll
 						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b + 1][k], r1, acc[k]);
+#ifdef MCHIP_EXP_SCATTER
+#pragma unroll
+						for (int k = 0; k < K; k++) unsafeAtomicAdd(&nacc[(size_t)row[b] * KP + k], q[k] * r0);
+#pragma unroll
+						for (int k = 0; k < K; k++) unsafeAtomicAdd(&nacc[(size_t)row[b + 1] * KP + k], q[k] * r1);
+#endif
 					}
 					if (SAFE) {
 						prod *= t[b];
@@ -1058,7 +1072,11 @@ void launch_accum_p(const mchip_pass_args &a, hipStream_t s)
 	else if (a.ploidy == 2) hipLaunchKernelGGL((k_column_pass<2, true, true, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
 	else hipLaunchKernelGGL((k_column_pass<0, true, true, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
 }
+#ifdef MCHIP_EXP_SCATTER
+inline size_t sparse_lds_bytes(const mchip_pass_args &a) { return (3 * (size_t)a.tile_cols * KP + QBLOCK) * sizeof(double); }
+#else
 inline size_t sparse_lds_bytes(const mchip_pass_args &a) { return (2 * (size_t)a.tile_cols * KP + QBLOCK) * sizeof(double); }
+#endif
 template <bool ACCUM> void launch_sparse(const mchip_pass_args &a, hipStream_t s)
 {
 	const size_t lds = sparse_lds_bytes(a);

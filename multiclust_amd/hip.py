@@ -21,7 +21,8 @@ class RunState(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libmulticlust_hip.so")
+    # MCHIP_LIB_PATH: an experimental build of the library (scripts/diag/*_exp.sh); the product path is the in-tree one
+    return os.environ.get("MCHIP_LIB_PATH") or os.path.join(_HERE, "lib", "libmulticlust_hip.so")
 
 
 _lib = None
