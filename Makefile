@@ -52,8 +52,16 @@ micro: scripts/micro/fp64_micro scripts/micro/op_cost
 scripts/micro/%: scripts/micro/%.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 
+# experiment behind profiles/r02_scatter_experiment.txt: the K = 8 kernels with MCHIP_EXP_SCATTER, linked with
+# the product's other objects into a library of its own; scripts/diag/scatter_exp.sh loads it through MCHIP_LIB_PATH
+exp-scatter: $(LIB)/libmulticlust_hip.so
+	@mkdir -p build/exp scripts/exp
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -DMCHIP_EXP_SCATTER -DMCHIP_K=8 -c multiclust_amd/csrc/mchip_kernels_k.hip -o build/exp/mchip_k8.o
+	$(HIPCC) --offload-arch=$(ARCH) --offload-compress -shared -fPIC -o scripts/exp/libmulticlust_hip_scatter.so \
+		$(filter-out $(OBJ)/mchip_k8.o,$(OBJ)/mchip.o $(OBJ)/mchip_comm.o $(KOBJ)) build/exp/mchip_k8.o -ldl
+
 clean:
-	rm -rf build $(LIB)/*.so $(BIN) scripts/micro/fp64_micro scripts/micro/op_cost
+	rm -rf build $(LIB)/*.so $(BIN) scripts/micro/fp64_micro scripts/micro/op_cost scripts/exp/*.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle micro clean
+.PHONY: all oracle micro exp-scatter clean

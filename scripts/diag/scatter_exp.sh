@@ -1,5 +1,6 @@
 # EXPERIMENT, not the product: the S-side pass with the N-side sums scattered into LDS accumulators by ds_add_f64
-# (kernel code under MCHIP_EXP_SCATTER, K = 8 object only; built by hand into scripts/exp/).
+# (kernel code under MCHIP_EXP_SCATTER, K = 8 object only; `make exp-scatter` builds scripts/exp/libmulticlust_hip_scatter.so;
+# DESIGN.md 4.3 (f)).
 # Prints the shipped passes and the experimental S-side pass at config 3's shape in alternation.
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
