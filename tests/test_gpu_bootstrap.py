@@ -131,3 +131,32 @@ def test_bootstrap_mixture_fit_initialises_like_the_reference():
     np.testing.assert_allclose(fit.get_q(0).ravel(), g.q("bsinit").ravel(), rtol=1e-15, atol=1e-18)
     np.testing.assert_allclose(fit.get_p(0), g.p("bsinit"), rtol=1e-15, atol=1e-18)
     fit.close()
+
+
+@pytest.mark.parametrize("name", ["multi_admix_k4", "tetra_admix_k3", "missing_admix_k3", "multi_admix_c_k3"])
+def test_tiled_and_chunked_generators_agree_on_the_reference_fixtures(ctx, name, monkeypatch):
+    """Both forms of both device generators on the reference's own bootstrap fixtures: the tiled ones (thread = individual x
+    locus tile, integer thresholds in LDS / counts taken as the partition is drawn) and the chunked ones (thread = 3 968
+    consecutive draws, stream-order intermediate + layout kernel) return the reference's data set and initial parameters."""
+    g = Golden(name)
+    window, _ = ob.glibc_window(g.m["bootstrap_seed"])
+    w0, _ = ob.glibc_window(g.m["seed"])
+    out = []
+    for knobs in ({}, {"MCHIP_SIM_NO_TILE": "1", "MCHIP_PART_NO_TILE": "1"}):
+        for k in ("MCHIP_SIM_NO_TILE", "MCHIP_PART_NO_TILE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        ctx.simulate_genotypes(g.I, g.L, g.ploidy, g.ua, window, g.K, g.q("bs"), g.p("bs"), eta_constrained=g.m["eta_constrained"])
+        sim = ctx.get_genotypes()
+        assert np.array_equal(counts_of(sim, g.ua), golden_bootstrap(g))
+        ctx.set_init_genotypes(g.geno)
+        ctx.set_model(g.K, eta_constrained=g.m["eta_constrained"], lower_bound=g.lower_bound)
+        ctx.mstep_from_rand_partition(w0, 0)
+        np.testing.assert_allclose(ctx.get_q(0), g.q("bsinit"), rtol=1e-15, atol=1e-18)
+        np.testing.assert_allclose(ctx.get_p(0), g.p("bsinit"), rtol=1e-15, atol=1e-18)
+        ll = ctx.em_step(0, 1)
+        out.append((sim, ctx.get_q(0), ctx.get_p(0), ll, ctx.get_p(1)))
+        ctx.set_init_genotypes(None)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
