@@ -335,6 +335,15 @@ def run_single_fit(args, env, name, ua, geno, steps, warmup, with_roofline=True)
         if fit.mod.fatal:
             raise SystemExit("EM stopped with fatal=%d" % fit.mod.fatal)
 
+    # clocks: a fresh process finds the GPU idle, and the W warm-up steps of a short run (50 ms at config 3, 1 ms at config 2) end
+    # before its clocks have come up -- the same kernels ran 3-10 % slower in the timed region than minutes into a long run.
+    # Log-likelihood passes over the resident data (no state changes) keep the device busy for --settle seconds first.
+    if args.settle > 0:
+        ll = C.c_double()
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < args.settle:
+            for _ in range(8):
+                hlib.mchip_loglik(ctx, fit.mod.pindex, C.byref(ll))
     for _ in range(warmup):
         one_step()
 
@@ -537,6 +546,8 @@ def main():
     ap.add_argument("--units", type=int, default=50, help="c4: random initialisations sharded over the GPUs")
     ap.add_argument("--replicates", type=int, default=200, help="c5: bootstrap replicates sharded over the GPUs")
     ap.add_argument("--streams", type=int, default=2, help="c5: concurrent replicates per GPU (host thread + contexts + streams each)")
+    ap.add_argument("--settle", type=float, default=1.5, help="seconds of untimed log-likelihood passes before the warm-up steps of a "
+                    "single-fit workload, so that the timed steps run at the clocks of a busy device (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra workloads carried on the default line (profiling "
