@@ -176,6 +176,20 @@ def check_step_and_cycle_on_slices(ctx, ua, geno, K, lb, q0, p0):
     check_simplex(qx, px, ua, lb)
     llx = ctx.loglik_prefetch(1)
     assert llx == ctx.loglik(1)
+    # the same cycle as ONE device-side batch (mchip_accel_run: stop rule, step size and accept test on the device; for diploid
+    # data the dual individual pass takes log L of the second iterate together with the extrapolated point's E step): slot 0
+    # ends on the extrapolated point if its log likelihood beats the second iterate's, else on the second iterate -- the very
+    # arrays the call-by-call sequence above produced
+    import ctypes as C
+    from multiclust_amd import hip
+    ll2 = ctx.loglik(2)
+    ctx.set_q(0, q0)
+    ctx.set_p(0, p0)
+    st = hip.RunState(logL=-np.inf, abs_error=1e-300, n_iter=0)
+    rc = ctx.lib.mchip_accel_run(ctx.h, 0, 3, 1, C.byref(st))
+    assert rc == 0 and st.fatal == 0 and st.n_iter == 2 and st.logL == ll1
+    want = (qx, px) if llx > ll2 else (q2, p2)
+    assert np.array_equal(ctx.get_q(0), want[0]) and np.array_equal(ctx.get_p(0), want[1])
     return qx, px, llx
 
 
