@@ -533,6 +533,21 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 					 * a bootstrap replicate lacks that allele) */
 					if (!NOMISS) t[b] = miss[b] ? 1.0 : t[b];
 				}
+				if constexpr (PL == 4 && !SAFE && ACCUM) {
+					/* tetraploid: the four copies of the locus share one reciprocal (rcp4's scheme: 16 issue slots per
+					 * locus instead of 20 for two pairs); the log-product takes the same two pair products as below */
+					const double p01 = t[0] * t[1], p23 = t[2] * t[3];
+					const double rp = rcp_full(p01 * p23);
+					const double r01 = rp * p23, r23 = rp * p01;
+					const double r[4] = { miss[0] ? 0.0 : r01 * t[1], miss[1] ? 0.0 : r01 * t[0],
+							      miss[2] ? 0.0 : r23 * t[3], miss[3] ? 0.0 : r23 * t[2] };
+#pragma unroll
+					for (int b = 0; b < 4; b++)
+#pragma unroll
+						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b][k], r[b], acc[k]);
+					prod *= p01;
+					prod *= p23;
+				} else
 #pragma unroll
 				for (int b = 0; b < PL; b += 2) {
 					const double pp = t[b] * t[b + 1];
@@ -623,6 +638,8 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 		/* unrolled with a scalar bound check per locus: static j keeps the genotype group and the offsets in registers (a
 		 * dynamic index would put them in scratch, whose s_waitcnt would also wait for the prefetches) */
 		const int nloc = l1 - lb * 8;
+		/* (diploid: taking two loci at a time so that four copies share one reciprocal, as the tetraploid locus does, needs the
+		 * four gathered rows at once -- 138 registers, three waves per SIMD -- and measured 8-10 % slower than this) */
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
 			if (j < nloc) one_locus(j);
