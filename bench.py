@@ -25,8 +25,9 @@ Workloads
 
 value = EM iterations/s summed over ranks (n_iter increments of stop(), em_alg.c:103, over the barrier-to-barrier wall time,
 max over ranks), inputs resident in HBM.  The same JSON line carries `roofline` for the dominant kernel (HIP events on the
-library's own stream) and, at N = 1, `cpu_baseline` (the CPU oracle on a bounded sample, rank 0; the oracle is only the
-baseline and the checker here, never the measured path) with `parity` = the HIP path on that same sample against it.
+library's own stream) and, at N = 1, `cpu_baseline` (the CPU oracle on a bounded sample, rank 0; one host core for the single
+fits, min(units, 16) processes at once -- one unit each -- for c4 and c5; the oracle is only the baseline and the checker here,
+never the measured path) with `parity` = the HIP path on that same sample against it.
 """
 import argparse
 import ctypes as C
@@ -197,9 +198,44 @@ def algorithmic_bytes(w, T, K=None):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline + parity
-def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0):
-    """The CPU oracle (oracle/mc_oracle.c, fused order, one host core) on a bounded sample of the same
-    workload: the first L_s loci of every individual, sized for about `budget_s` seconds."""
+def cpu_oracle_run(ob, I, Ls, p, K, ua_s, geno_s, q0, p0, lb, accel, iters):
+    """`iters` EM iterations of the CPU oracle (fused order) from (q0, p0): (model, seconds)"""
+    opt = ob.make_options(lower_bound=lb, fused=1, accel_scheme=accel, abs_error=1e-300)
+    mod = ob.Model(ob.Data(I, Ls, p, ua_s, geno_s), opt, K)
+    mod.q(0)[...] = q0
+    mod.p(0)[...] = p0
+    t0 = time.perf_counter()
+    if accel:
+        for _ in range(iters // 2):
+            mod.accelerated_em_step()
+    else:
+        for _ in range(iters):
+            mod.em_step()
+    return mod, time.perf_counter() - t0
+
+
+def cpu_worker(path):
+    """One more host core of a multi-unit cpu_baseline (c4, c5): a child process of bench.py's cpu_baseline leg that never
+    touches the GPU.  Loads the sample the parent wrote, says "ready", waits for "go" on stdin, runs the same oracle
+    iterations from its own starting point and prints {"iters", "dt"}."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_bind as ob
+    d = np.load(path)
+    I, Ls, p = d["geno"].shape
+    K, accel, iters, lb = int(d["K"]), int(d["accel"]), int(d["iters"]), float(d["lb"])
+    ua_s, geno_s = np.ascontiguousarray(d["ua"]), np.ascontiguousarray(d["geno"])
+    q0, p0 = np.ascontiguousarray(d["q0"]), np.ascontiguousarray(d["p0"])
+    print("ready", flush=True)
+    sys.stdin.readline()
+    mod, dt = cpu_oracle_run(ob, I, Ls, p, K, ua_s, geno_s, q0, p0, lb, accel, iters)
+    print(json.dumps({"iters": int(mod.n_iter), "dt": dt}), flush=True)
+
+
+def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0, units=1):
+    """The CPU oracle (oracle/mc_oracle.c, fused order) on a bounded sample of the same workload: the first L_s loci of every
+    individual, sized for about `budget_s` seconds of one host core.  A workload of independent units (c4's initialisations,
+    c5's replicates: SURVEY.md 8d, the reference's own scaling model) is timed on min(units, host cores) processes at once,
+    each fitting one unit's worth of the sample; `value` is then the sum of their rates and `cores` their number."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bind as ob
     from synth import random_params
@@ -212,19 +248,37 @@ def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0):
     geno_s = np.ascontiguousarray(geno[:, :Ls, :])
     lb = ob.lib.mco_lower_bound(1e-8, I, p)
     q0, p0 = random_params(I, ua_s, K, seed=11, lower_bound=lb)
-    opt = ob.make_options(lower_bound=lb, fused=1, accel_scheme=accel, abs_error=1e-300)
-    mod = ob.Model(ob.Data(I, Ls, p, ua_s, geno_s), opt, K)
-    mod.q(0)[...] = q0
-    mod.p(0)[...] = p0
-    t0 = time.perf_counter()
-    if accel:
-        for _ in range(iters // 2):
-            mod.accelerated_em_step()
-    else:
-        for _ in range(iters):
-            mod.em_step()
-    dt = time.perf_counter() - t0
+    # a one-GPU box shares its host: 16 cores are this process's to use, whatever os.cpu_count() says (and every worker
+    # holds its own copy of the sample)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = os.cpu_count() or 1
+    procs = max(1, min(units, avail, 16))
+    workers, tmp = [], None
+    if procs > 1:
+        import tempfile
+        tmp = tempfile.NamedTemporaryFile(suffix=".npz", delete=False)
+        tmp.close()
+        np.savez(tmp.name, ua=ua_s, geno=geno_s, q0=q0, p0=p0, K=K, accel=accel, iters=iters, lb=lb)
+        for _ in range(procs - 1):
+            workers.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", tmp.name],
+                                            stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+        for wk in workers:
+            if wk.stdout.readline().strip() != "ready":
+                raise SystemExit("cpu_baseline worker failed to start")
+        for wk in workers:
+            wk.stdin.write("go\n")
+            wk.stdin.flush()
+    mod, dt = cpu_oracle_run(ob, I, Ls, p, K, ua_s, geno_s, q0, p0, lb, accel, iters)
     it_s_sample = mod.n_iter / dt
+    rates = [it_s_sample]
+    for wk in workers:
+        r = json.loads(wk.stdout.readline())
+        wk.wait()
+        rates.append(r["iters"] / r["dt"])
+    if tmp:
+        os.unlink(tmp.name)
     # the same sample, parameters and iterations through the HIP path: "logL delta vs ref" of BASELINE.json's metric,
     # measured in this run (the oracle is the checker here, as in tests/)
     from multiclust_amd import host
@@ -242,11 +296,13 @@ def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0):
         "note": "HIP path vs CPU oracle on the cpu_baseline sample, same parameters and iterations; Q/P entries > 1e-6",
     }
     fit.close()
+    how = "on one core" if procs == 1 else "on each of %d processes at once (one unit each; rates summed: %.3f-%.3f it/s per process)" % (
+        procs, min(rates), max(rates))
     return {
-        "value": it_s_sample * Ls / L, "unit": "EM iterations/s", "cores": 1, "kind": "port",
-        "sample": "first %d of %d loci, all %d individuals, %d EM iterations (%s) in %.1f s on one core; "
-                  "scaled by %d/%d (cost is linear in loci)" % (Ls, L, I, mod.n_iter, "SQUAREM-3 cycles" if accel else "plain EM", dt, Ls, L),
-        "sample_value": it_s_sample, "parity": parity,
+        "value": sum(rates) * Ls / L, "unit": "EM iterations/s", "cores": procs, "kind": "port",
+        "sample": "first %d of %d loci, all %d individuals, %d EM iterations (%s) in %.1f s %s; "
+                  "scaled by %d/%d (cost is linear in loci)" % (Ls, L, I, mod.n_iter, "SQUAREM-3 cycles" if accel else "plain EM", dt, how, Ls, L),
+        "sample_value": sum(rates), "parity": parity,
     }
 
 
@@ -537,6 +593,9 @@ def finish(env, args, out, scaling):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":      # child of the cpu_baseline leg: CPU only
+        cpu_worker(sys.argv[2])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -567,7 +626,7 @@ def main():
         ua, geno = workload_data(w, env)
         out = run_bootstrap(env, w, ua, geno, args.replicates, args.steps, n_streams=args.streams)
         if want_cpu:
-            out["cpu_baseline"] = cpu_baseline(w, ua, geno, 0, args.cpu_budget, env.local_rank)
+            out["cpu_baseline"] = cpu_baseline(w, ua, geno, 0, args.cpu_budget, env.local_rank, units=args.replicates)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         if env.rank == 0:
             finish(env, args, out, "strong")
@@ -583,7 +642,7 @@ def main():
         out = run_units(env, fit, w, T, args.units, args.steps, args.warmup)
         fit.close()
         if want_cpu:
-            out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget, env.local_rank)
+            out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget, env.local_rank, units=args.units)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         if env.rank == 0:
             finish(env, args, out, "strong")
