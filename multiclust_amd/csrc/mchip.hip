@@ -1628,7 +1628,9 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	}
 	ctx->n_ichunks = (ctx->I + ctx->ichunk - 1) / ctx->ichunk;
 	/* individual pass: slab bytes per chunk 8*K*I, genotype bytes per chunk lchunk*I*ploidy */
-	const int ind_tiles = (ctx->I + MCHIP_QBLOCK - 1) / MCHIP_QBLOCK;
+	/* (the sparse pass gives an individual mchip_ind_split(K) lanes; the dense and mixture kernels one, and do not use n_ll_ind) */
+	const int ind_per_block = mchip_qblock(K) / (admixture ? mchip_ind_split(K) : 1);
+	const int ind_tiles = (ctx->I + ind_per_block - 1) / ind_per_block;
 	int min_lchunk = (int)ceil(8.0 * K / (slab_frac * ctx->ploidy));
 	target = per_cu_ind * ctx->n_cu;
 	want = (target + ind_tiles - 1) / ind_tiles;
@@ -1641,8 +1643,8 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	ctx->n_ll_col = col_tiles * ctx->n_ichunks;
 	ctx->n_ll_ind = ind_tiles * ctx->n_lchunks;
 	{	/* the sparse individual pass stages two tiles of 8 loci of P rows in LDS: use it while they fit 64 KiB */
-		const size_t kp = (size_t)(((K + 1) & ~1) + ((K % 16 == 0) ? 2 : 0));	/* KP of mchip_kernels_k.hip */
-		const size_t lds = (2 * 8 * (size_t)ctx->max_M * kp + MCHIP_QBLOCK) * sizeof(double);
+		const size_t kp = (size_t)mchip_kp(K);
+		const size_t lds = (2 * 8 * (size_t)ctx->max_M * kp + mchip_qblock(K)) * sizeof(double);
 		ctx->sparse = (ctx->max_M <= MCHIP_SPARSE_MAX_M) && lds <= 65536 && !getenv("MCHIP_FORCE_DENSE");
 	}
 	ctx->n_llpart = ctx->n_ll_col > ctx->n_ll_ind ? ctx->n_ll_col : ctx->n_ll_ind;

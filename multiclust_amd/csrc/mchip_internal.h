@@ -27,6 +27,24 @@
 #define MCHIP_QBLOCK 128	/* individuals per workgroup of the individual-side kernels (lane = individual) */
 #endif	/* sparse individual pass is used when no locus has more alleles than this */
 
+/* Sparse individual pass: lanes that share one individual, each holding a range of k (its part of q, of the S-side sums and of
+ * every gathered P row; the partial dot products are combined across the lanes).  One lane holds 4K doubles: above K = 24 that
+ * leaves one or two waves per SIMD (292 registers at K = 32), above 32 it spills. */
+constexpr int mchip_ind_split(int K) { return K <= 24 ? 1 : (K <= 48 ? 2 : 4); }
+/* lanes per workgroup of the individual-side kernels: the staged P tile of a workgroup grows with K (34 KB at K = 64), so the
+ * largest K share it among four waves instead of two, or LDS capacity would leave two waves per SIMD */
+constexpr int mchip_qblock(int K) { return K > 48 ? 2 * MCHIP_QBLOCK : MCHIP_QBLOCK; }
+/* LDS row stride of the staged P tiles in doubles: rows stay 16-byte aligned and hold the lanes' k ranges (each padded to an even
+ * count); a stride of 128 or 256 bytes would put the rows of a locus on the same banks (64 banks x 4 bytes), so multiples of 16
+ * get two doubles of padding */
+constexpr int mchip_kp(int K)
+{
+	const int split = mchip_ind_split(K);
+	const int per_lane = ((((K + split - 1) / split) + 1) & ~1) * split;
+	const int base = per_lane > ((K + 1) & ~1) ? per_lane : ((K + 1) & ~1);
+	return base + ((base % 16 == 0) ? 2 : 0);
+}
+
 enum { MCHIP_KERN_ACCUM_P = 0, MCHIP_KERN_ACCUM_Q = 1, MCHIP_KERN_LOGLIK = 2, MCHIP_KERN_DUAL = 3, MCHIP_KERN_COUNT = 4 };
 
 /* arguments of the two streaming passes over the genotype matrix */

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 }
 
 /* ---------------------------------------------------------------- individual pass */
-constexpr int QBLOCK = MCHIP_QBLOCK;
+constexpr int QBLOCK = mchip_qblock(K);
 
 template <int PL>
 __global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
@@ -393,9 +393,22 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_pass(mchip_pass_args a)
  * ds_read_b128; rows of one locus are consecutive, so lanes on different alleles hit different bank groups.
  * Produces the S-side sums and the log likelihood (one multiply per copy, no selects).  ACCUM = false is the
  * stand-alone log-likelihood pass (logL_admixture, log_likelihood.c:96-147). */
-/* LDS row stride in doubles: rows stay 16-byte aligned; a stride of 128 or 256 bytes would put the rows of a locus on the
- * same banks (64 banks x 4 bytes), so K = 16 and K = 32 get two doubles of padding */
-constexpr int KP = ((K + 1) & ~1) + ((K % 16 == 0) ? 2 : 0);
+/* LDS row stride in doubles (mchip_internal.h) and the lane split of the sparse individual pass: SPLIT lanes per individual,
+ * lane part s holds k in [s * KSP, (s + 1) * KSP) (KS values, KSP = KS rounded up to even; slots past K hold zeros) */
+constexpr int KP = mchip_kp(K);
+constexpr int SPLIT = mchip_ind_split(K);
+constexpr int KS = (K + SPLIT - 1) / SPLIT;
+constexpr int KSP = SPLIT == 1 ? K : ((KS + 1) & ~1);	/* doubles a lane works on */
+constexpr int KGP = SPLIT == 1 ? KP / 2 : KSP / 2;	/* 16-byte LDS reads per gathered row part */
+static_assert(SPLIT * ((KS + 1) & ~1) <= KP || SPLIT == 1, "row stride holds every lane's range");
+
+/* sum over the SPLIT adjacent lanes of an individual; every lane ends with the same bits (a + b = b + a at every level) */
+__device__ __forceinline__ double split_sum(double v)
+{
+	if (SPLIT >= 2) v += __shfl_xor(v, 1);
+	if (SPLIT >= 4) v += __shfl_xor(v, 2);
+	return v;
+}
 
 #ifndef MCHIP_SPARSE_WAVES
 #define MCHIP_SPARSE_WAVES 1
@@ -433,16 +446,23 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 	double *nacc = red + QBLOCK;
 	for (int x = threadIdx.x; x < a.tile_cols * KP; x += QBLOCK) nacc[x] = 0.0;
 #endif
-	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
+	static_assert(!DUAL || SPLIT == 1, "dual pass: one lane per individual");
+	const int part = SPLIT == 1 ? 0 : (int)(threadIdx.x % SPLIT);	/* which k range this lane holds */
+	const int k0 = part * KSP;
+	const int i_raw = blockIdx.x * (QBLOCK / SPLIT) + threadIdx.x / SPLIT;
 	const bool active = i_raw < a.I;
 	const int i = active ? i_raw : a.I - 1;
 	const int pl = PL ? PL : a.ploidy;
-	double q[K], acc[K], q2[DUAL ? K : 1];
+	double q[KSP], acc[KSP], q2[DUAL ? K : 1];
 #pragma unroll
-	for (int k = 0; k < K; k++) {
-		q[k] = a.Q[(size_t)i * a.qstride + k];
+	for (int k = 0; k < KSP; k++) {
+		q[k] = (SPLIT == 1 || k0 + k < K) ? a.Q[(size_t)i * a.qstride + k0 + k] : 0.0;
 		acc[k] = 0.0;
 		if constexpr (DUAL) q2[k] = a.Q2[(size_t)i * a.qstride + k];
+	}
+	if constexpr (SPLIT > 1) {	/* the row slots past K are read by the last lane part: zeros, once (staging writes k < K only) */
+		for (int x = threadIdx.x; x < 2 * a.tile_cols * KP; x += QBLOCK) lds[x] = 0.0;
+		__syncthreads();
 	}
 	const int l0 = blockIdx.y * a.lchunk;
 	const int l1 = min(a.L, l0 + a.lchunk);
@@ -507,7 +527,7 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 			const int base = tb[j] - c_lo;
 			if constexpr (PL == 2 || PL == 4) {
 				/* all copies of the locus first (t), then one shared reciprocal for each pair of copies */
-				double pc[PL ? PL : 1][KP], t[PL ? PL : 1];
+				double pc[PL ? PL : 1][2 * KGP], t[PL ? PL : 1];
 				bool miss[PL ? PL : 1];
 				unsigned row[PL ? PL : 1];
 #pragma unroll
@@ -518,16 +538,17 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 					const unsigned mm = miss[b] ? 0u : mraw;
 					row[b] = (unsigned)base + mm;
 					/* 16-byte LDS reads (ds_read_b128): twice the bytes per LDS cycle of ds_read2_b64 */
-					const double2 *pr = reinterpret_cast<const double2 *>(tile + (size_t)(base + (int)mm) * KP);
+					const double2 *pr = reinterpret_cast<const double2 *>(tile + (size_t)(base + (int)mm) * KP + k0);
 #pragma unroll
-					for (int k = 0; k < KP / 2; k++) {
+					for (int k = 0; k < KGP; k++) {
 						const double2 v = pr[k];
 						pc[b][2 * k] = v.x;
 						pc[b][2 * k + 1] = v.y;
 					}
 					t[b] = q[0] * pc[b][0];
 #pragma unroll
-					for (int k = 1; k < K; k++) t[b] = __builtin_fma(q[k], pc[b][k], t[b]);
+					for (int k = 1; k < KSP; k++) t[b] = __builtin_fma(q[k], pc[b][k], t[b]);
+					t[b] = split_sum(t[b]);	/* the lanes' partial dot products; identical in all of them afterwards */
 					/* a missing copy borrowed column 0 of its locus; it takes t = 1 so that it leaves the log-product and
 					 * its partner's shared reciprocal alone, whatever column 0 holds (all zeros when projection is off and
 					 * a bootstrap replicate lacks that allele) */
@@ -544,7 +565,7 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 #pragma unroll
 					for (int b = 0; b < 4; b++)
 #pragma unroll
-						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b][k], r[b], acc[k]);
+						for (int k = 0; k < KSP; k++) acc[k] = __builtin_fma(pc[b][k], r[b], acc[k]);
 					prod *= p01;
 					prod *= p23;
 				} else
@@ -562,9 +583,9 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 							r1 = miss[b + 1] ? 0.0 : rp * t[b];
 						}
 #pragma unroll
-						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b][k], r0, acc[k]);
+						for (int k = 0; k < KSP; k++) acc[k] = __builtin_fma(pc[b][k], r0, acc[k]);
 #pragma unroll
-						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b + 1][k], r1, acc[k]);
+						for (int k = 0; k < KSP; k++) acc[k] = __builtin_fma(pc[b + 1][k], r1, acc[k]);
 #ifdef MCHIP_EXP_SCATTER
 #pragma unroll
 						for (int k = 0; k < K; k++) unsafeAtomicAdd(&nacc[(size_t)row[b] * KP + k], q[k] * r0);
@@ -607,17 +628,18 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 					const unsigned mraw = g.copy(j, bb, pl);
 					const bool miss = (mraw == MCHIP_MISSING) || !active;
 					const unsigned mm = miss ? 0u : mraw;
-					const double *pr = tile + (size_t)(base + (int)mm) * KP;
-					double pc[K];
+					const double *pr = tile + (size_t)(base + (int)mm) * KP + k0;
+					double pc[KSP];
 #pragma unroll
-					for (int k = 0; k < K; k++) pc[k] = pr[k];
+					for (int k = 0; k < KSP; k++) pc[k] = pr[k];
 					double t = q[0] * pc[0];
 #pragma unroll
-					for (int k = 1; k < K; k++) t = __builtin_fma(q[k], pc[k], t);
+					for (int k = 1; k < KSP; k++) t = __builtin_fma(q[k], pc[k], t);
+					t = split_sum(t);
 					if (ACCUM) {
 						const double r = miss ? 0.0 : rcp_full(t);
 #pragma unroll
-						for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[k], r, acc[k]);
+						for (int k = 0; k < KSP; k++) acc[k] = __builtin_fma(pc[k], r, acc[k]);
 					}
 					prod *= miss ? 1.0 : t;
 					rescale(prod, ex);
@@ -659,11 +681,13 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 	}
 	const double ll = (double)ex * 0.693147180559945309417 + log(prod);
 	if (ACCUM && active) {
-		double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
+		double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K + k0;
 #pragma unroll
-		for (int k = 0; k < K; k++) out[k] = acc[k];
+		for (int k = 0; k < KSP; k++)
+			if (SPLIT == 1 || k0 + k < K) out[k] = acc[k];
 	}
-	const double tot = block_sum<QBLOCK>(active ? ll : 0.0, red);
+	/* every lane of an individual carries the same log-product: part 0 speaks for it */
+	const double tot = block_sum<QBLOCK>((active && part == 0) ? ll : 0.0, red);
 	if (threadIdx.x == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
 	if (DUAL) {
 		const double ll2 = (double)ex2 * 0.693147180559945309417 + log(prod2);
@@ -1070,6 +1094,7 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_project_q(int nrows, double *Q,
 /* ---------------------------------------------------------------- launchers */
 inline dim3 column_grid(const mchip_pass_args &a) { return dim3((a.T + MCHIP_BLOCK - 1) / MCHIP_BLOCK, a.n_ichunks); }
 inline dim3 indiv_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK - 1) / QBLOCK, a.n_lchunks); }
+inline dim3 sparse_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK / SPLIT - 1) / (QBLOCK / SPLIT), a.n_lchunks); }
 
 /* a.sparse: the column pass only accumulates the N-side sums; S-side sums and logL come from the sparse
  * individual pass.  Otherwise (loci with more alleles than the LDS tile is sized for) the dense pair is used:
@@ -1102,7 +1127,7 @@ template <bool ACCUM> void launch_sparse(const mchip_pass_args &a, hipStream_t s
 	/* measured (profiles/r02_biallelic_variant.txt): the stand-alone log-likelihood pass gains 6-21 % from K = 6 up (it is
 	 * LDS-bound in the general kernel), the S-side pass only from K = 10 (it is FP64-bound, and the dense-over-two-alleles
 	 * form costs more instructions per locus: +8-19 % below that) */
-	constexpr bool bial_pays = ACCUM ? (K >= 10) : (K >= 6);
+	constexpr bool bial_pays = SPLIT == 1 && (ACCUM ? (K >= 10) : (K >= 6));	/* (its grid and partials are one lane per individual) */
 	if (bial_pays && a.biallelic && a.ploidy == 2 && !safe) {
 		if (nomiss) hipLaunchKernelGGL((k_individual_bial<ACCUM, true>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
 		else hipLaunchKernelGGL((k_individual_bial<ACCUM, false>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
@@ -1110,13 +1135,13 @@ template <bool ACCUM> void launch_sparse(const mchip_pass_args &a, hipStream_t s
 	}
 #define MCHIP_SPARSE(PLV) \
 	do { \
-		if (nomiss && !safe) hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, false, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a); \
-		else if (!safe) hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, false, false>), indiv_grid(a), dim3(QBLOCK), lds, s, a); \
-		else hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, true, false>), indiv_grid(a), dim3(QBLOCK), lds, s, a); \
+		if (nomiss && !safe) hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, false, true>), sparse_grid(a), dim3(QBLOCK), lds, s, a); \
+		else if (!safe) hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, false, false>), sparse_grid(a), dim3(QBLOCK), lds, s, a); \
+		else hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, true, false>), sparse_grid(a), dim3(QBLOCK), lds, s, a); \
 	} while (0)
 	if (a.ploidy == 2) MCHIP_SPARSE(2);
 	else if (a.ploidy == 4) MCHIP_SPARSE(4);
-	else hipLaunchKernelGGL((k_individual_sparse<0, ACCUM, true, false>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
+	else hipLaunchKernelGGL((k_individual_sparse<0, ACCUM, true, false>), sparse_grid(a), dim3(QBLOCK), lds, s, a);
 #undef MCHIP_SPARSE
 }
 /* the dual pass exists where both of its halves would run the sparse kernel with shared reciprocals (so that its results are
