@@ -22,15 +22,15 @@
 #include "multiclust_hip.h"
 
 #define MCHIP_BLOCK 256
-#define MCHIP_SPARSE_MAX_M 32
+#define MCHIP_SPARSE_MAX_M 32	/* sparse individual pass is used when no locus has more alleles than this */
 #ifndef MCHIP_QBLOCK
 #define MCHIP_QBLOCK 128	/* individuals per workgroup of the individual-side kernels (lane = individual) */
-#endif	/* sparse individual pass is used when no locus has more alleles than this */
+#endif
 
 /* Sparse individual pass: lanes that share one individual, each holding a range of k (its part of q, of the S-side sums and of
- * every gathered P row; the partial dot products are combined across the lanes).  One lane holds 4K doubles: above K = 24 that
+ * every gathered P row; the partial dot products are combined across the lanes).  One lane holds 4K doubles: above K = 27 that
  * leaves one or two waves per SIMD (292 registers at K = 32), above 32 it spills. */
-constexpr int mchip_ind_split(int K) { return K <= 24 ? 1 : (K <= 48 ? 2 : 4); }
+constexpr int mchip_ind_split(int K) { return K <= 27 ? 1 : (K <= 48 ? 2 : 4); }
 /* lanes per workgroup of the individual-side kernels: the staged P tile of a workgroup grows with K (34 KB at K = 64), so the
  * largest K share it among four waves instead of two, or LDS capacity would leave two waves per SIMD */
 constexpr int mchip_qblock(int K) { return K > 48 ? 2 * MCHIP_QBLOCK : MCHIP_QBLOCK; }
