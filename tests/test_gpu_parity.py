@@ -364,3 +364,43 @@ def test_every_K_both_individual_side_variants_agree(ctx, ploidy, bound, project
         ctx.set_p(0, p0)
         a, b = ctx.loglik(0), ctx.e_step(0)
         assert np.isfinite(a) and a == b, (K, a, b)
+
+
+@pytest.mark.parametrize("I,L,K,pl,maxal,miss", [(300, 257, 49, 2, 4, 0.0), (129, 300, 64, 2, 3, 0.03), (257, 129, 56, 4, 4, 0.0),
+                                                 (200, 200, 33, 3, 5, 0.02), (300, 300, 28, 2, 4, 0.0), (150, 400, 27, 2, 4, 0.01)])
+def test_large_k_mixture_and_shared_eta_models(ctx, I, L, K, pl, maxal, miss):
+    """K on both sides of the lane split of the sparse individual pass (one lane per individual up to K = 27, two up to 48,
+    four and 256-lane workgroups above) for the models that share its kernels and workgroup size: the mixture model
+    (k_mix_gather / k_mix_finalize) and the admixture model with shared mixing proportions (-c), two EM steps against the oracle."""
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=pl, max_alleles=maxal, seed=K, missing=miss)
+    lb = ob.lib.mco_lower_bound(1e-8, I, pl)
+    _, p0 = random_params(I, ua, K, seed=K + 1, lower_bound=lb)
+    eta0 = np.full(K, 1.0 / K)
+    opt = ob.make_options(admixture=0, lower_bound=lb, abs_error=0.0)
+    mod = ob.Model(ob.Data(I, L, pl, ua, geno), opt, K)
+    mod.q(0)[...] = eta0
+    mod.p(0)[...] = p0
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, admixture=0, lower_bound=lb)
+    ctx.set_q(0, eta0)
+    ctx.set_p(0, p0)
+    for s in (1, 2):
+        mod.em_step()
+        ll = ctx.em_step(0, 0)
+        assert abs(ll - mod.logL) <= max(1e-8, 1e-12 * abs(mod.logL)), (s, ll, mod.logL)
+        np.testing.assert_allclose(ctx.get_q(0), mod.q(0), rtol=1e-7, atol=1e-13)
+        np.testing.assert_allclose(ctx.get_p(0), mod.p(0), rtol=1e-7, atol=1e-13)
+    q0, p0 = random_params(I, ua, K, seed=K + 2, lower_bound=lb)
+    opt = ob.make_options(lower_bound=lb, fused=1, abs_error=0.0, eta_constrained=1)
+    mod = ob.Model(ob.Data(I, L, pl, ua, geno), opt, K)
+    mod.q(0)[...] = q0[0]
+    mod.p(0)[...] = p0
+    ctx.set_model(K, eta_constrained=1, lower_bound=lb)
+    ctx.set_q(0, np.ascontiguousarray(q0[0]))
+    ctx.set_p(0, p0)
+    for s in (1, 2):
+        mod.em_step()
+        ll = ctx.em_step(0, 0)
+        assert abs(ll - mod.logL) <= max(1e-8, 1e-12 * abs(mod.logL)), ("c", s, ll, mod.logL)
+        np.testing.assert_allclose(ctx.get_q(0), mod.q(0), rtol=1e-8, atol=1e-14)
+        np.testing.assert_allclose(ctx.get_p(0), mod.p(0), rtol=1e-8, atol=1e-14)
