@@ -890,7 +890,37 @@ __device__ void michelot_strided(double *x, int stride, int len, double mn, uint
 	}
 }
 
-/* P[to][l,.][k] = normalise(P[from] * sum_chunks Apart) then project (em_alg.c:706-752); thread = (l,k) */
+/* simplex.c:109-143 on up to 8 values held in registers (static indices; entries past len are ignored): the arithmetic of
+ * michelot_strided, operation for operation */
+__device__ __forceinline__ void michelot_small(double (&x)[8], int len, double mn)
+{
+	unsigned fixed = 0u;
+	int n = len;
+	while (n) {
+		double csum = 0.0;
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			if (j < len) csum += x[j];
+		const double shift = (csum - 1.0) / (double)n;
+		bool can_terminate = true;
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			if (j >= len || ((fixed >> j) & 1u)) continue;
+			double v = x[j] - shift;
+			if (v < mn) {
+				v = mn;
+				fixed |= 1u << j;
+				n--;
+				can_terminate = false;
+			}
+			x[j] = v;
+		}
+		if (can_terminate) break;
+	}
+}
+
+/* P[to][l,.][k] = normalise(P[from] * sum_chunks Apart) then project (em_alg.c:706-752); thread = (l,k).  Loci with at most 8
+ * alleles (nearly always) are summed, normalised and projected in registers and written once; longer ones go through memory */
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_p(int L, int K, int T, const int32_t *__restrict__ toff,
 		int n_ichunks, const double *__restrict__ Apart, const double *Pfrom, double *Pto,
 		int weighted, double add_lb, int do_projection, double lb, uint8_t *flags, const int *stop = nullptr)
@@ -901,6 +931,29 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_p(int L, int K, int T,
 	const int l = (int)(idx / K);
 	const int c0 = toff[l], M = toff[l + 1] - c0;
 	double temp = 0.0;
+	if (M <= 8) {
+		double v[8];
+#pragma unroll
+		for (int m = 0; m < 8; m++) {
+			v[m] = 0.0;
+			if (m < M) {
+				const size_t e = (size_t)(c0 + m) * K + k;
+				double s = ordered_sum(0.0, Apart, e, (size_t)T * K, n_ichunks);
+				if (weighted) s *= Pfrom[e];
+				s += add_lb;
+				v[m] = s;
+				temp += s;
+			}
+		}
+#pragma unroll
+		for (int m = 0; m < 8; m++)
+			if (m < M) v[m] /= temp;
+		if (do_projection) michelot_small(v, M, lb);
+#pragma unroll
+		for (int m = 0; m < 8; m++)
+			if (m < M) Pto[(size_t)(c0 + m) * K + k] = v[m];
+		return;
+	}
 	for (int m = 0; m < M; m++) {
 		const size_t e = (size_t)(c0 + m) * K + k;
 		double s = ordered_sum(0.0, Apart, e, (size_t)T * K, n_ichunks);
@@ -922,6 +975,16 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_project_p(int L, int K, const i
 	const int k = (int)(idx % K);
 	const int l = (int)(idx / K);
 	const int c0 = toff[l], M = toff[l + 1] - c0;
+	if (M <= 8) {
+		double v[8];
+#pragma unroll
+		for (int m = 0; m < 8; m++) v[m] = m < M ? P[(size_t)(c0 + m) * K + k] : 0.0;
+		michelot_small(v, M, lb);
+#pragma unroll
+		for (int m = 0; m < 8; m++)
+			if (m < M) P[(size_t)(c0 + m) * K + k] = v[m];
+		return;
+	}
 	michelot_strided(P + (size_t)c0 * K + k, K, M, lb, flags ? flags + (size_t)c0 * K + k : nullptr);
 }
 
