@@ -1909,9 +1909,19 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 			int rc = finalize_shared_eta(ctx, to, stop);
 			if (rc) return rc;
 		}
-		hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
-				   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
-				   1, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags, stop);
+		if (ctx->n_ichunks > 8 && !getenv("MCHIP_NO_SLAB_SUM")) {
+			/* many N-side slabs: k_sum_slabs adds them at 5 TB/s (element- and slab-level parallelism, fully coalesced; the
+			 * (l, k) threads of k_finalize_p reach 2.7 TB/s on the same bytes), k_finalize_p then reads one slab */
+			const size_t n = (size_t)ctx->K * ctx->T;
+			hipLaunchKernelGGL(k_sum_slabs, dim3(nblk(n, 32)), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_Apart, ctx->n_ichunks, n, ctx->d_stage, stop);
+			hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
+					   ctx->L, ctx->K, ctx->T, ctx->d_toff, 1, ctx->d_stage, ctx->d_p[from], ctx->d_p[to],
+					   1, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags, stop);
+		} else {
+			hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
+					   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
+					   1, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags, stop);
+		}
 	}
 	HIPCHK(hipGetLastError());
 	ctx->have_ll = 1;
