@@ -840,6 +840,27 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_sum(const double *__rest
 	if (threadIdx.x == 0) *out = red[0];
 }
 
+/* the 2 * nout sums of a dot-product pass in one launch (block x < nout: eta part x -> sc[16 + x]; the others: p part -> sc[20 + .]):
+ * each block is k_reduce_sum on its array, same order, same tree */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_dots(const double *__restrict__ part_q, int gq, const double *__restrict__ part_p, int gp,
+		int nout, double *sc, const int *stop)
+{
+	__shared__ double red[MCHIP_BLOCK];
+	if (stop && *stop) return;
+	const int x = blockIdx.x;
+	const double *in = x < nout ? part_q + (size_t)x * gq : part_p + (size_t)(x - nout) * gp;
+	const int n = x < nout ? gq : gp;
+	double *out = x < nout ? sc + 16 + x : sc + 20 + (x - nout);
+	const double s = (int)threadIdx.x < n ? ordered_sum(0.0, in, threadIdx.x, MCHIP_BLOCK, (n - (int)threadIdx.x + MCHIP_BLOCK - 1) / MCHIP_BLOCK) : 0.0;
+	red[threadIdx.x] = s;
+	__syncthreads();
+	for (int w = MCHIP_BLOCK / 2; w > 0; w >>= 1) {
+		if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *out = red[0];
+}
+
 /* out[e] = sum over slabs of slabs[j][e], in a fixed order: a block handles 32 elements x 8 slab lanes (lane s adds
  * slabs s, s+8, ...; the 8 partial sums are then added in lane order), so the many per-chunk partial-sum slabs of the
  * individual pass are combined with element- AND slab-level parallelism instead of one serial loop per individual */
@@ -1112,6 +1133,48 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_dots(const double *__restrict__
 		part[gridDim.x + blockIdx.x] = red[1][0];
 		part[2 * gridDim.x + blockIdx.x] = red[2][0];
 	}
+}
+
+/* k_dots (mode 0) and k_accel_update of a batched cycle straight from the three iterates: u = x1 - x0 and v = x2 - x1 are formed
+ * where they are used -- the values k_diff would have stored, so the sums and the update keep their bits -- and the cycle has
+ * four launches and 100 MB of traffic less */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_dots_slots(const double *__restrict__ x0, const double *__restrict__ x1,
+		const double *__restrict__ x2, size_t n, double *part, const int *stop)
+{
+	__shared__ double red[3][MCHIP_BLOCK];
+	if (stop && *stop) return;
+	double s0 = 0, s1 = 0, s2 = 0;
+	for (size_t x = (size_t)blockIdx.x * MCHIP_BLOCK + threadIdx.x; x < n; x += (size_t)gridDim.x * MCHIP_BLOCK) {
+		const double uu = x1[x] - x0[x], vv = x2[x] - x1[x];
+		const double d = vv - uu;
+		s0 += uu * uu; s1 += uu * d; s2 += d * d;
+	}
+	red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+	__syncthreads();
+	for (int w = MCHIP_BLOCK / 2; w > 0; w >>= 1) {
+		if ((int)threadIdx.x < w) {
+			red[0][threadIdx.x] += red[0][threadIdx.x + w];
+			red[1][threadIdx.x] += red[1][threadIdx.x + w];
+			red[2][threadIdx.x] += red[2][threadIdx.x + w];
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		part[blockIdx.x] = red[0][0];
+		part[gridDim.x + blockIdx.x] = red[1][0];
+		part[2 * gridDim.x + blockIdx.x] = red[2][0];
+	}
+}
+__global__ void k_accel_update_slots(const double *__restrict__ x0, const double *x1, const double *__restrict__ x2, double *out, size_t n,
+				     int qn_form, const double *s_dev, const int *stop)
+{
+#pragma clang fp contract(off)
+	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= n || (stop && *stop)) return;
+	const double s = *s_dev;
+	const double u = x1[idx] - x0[idx], v = x2[idx] - x1[idx];	/* (out may be x1: read before written, element by element) */
+	if (qn_form) out[idx] = x0[idx] + u + s * v;
+	else out[idx] = x0[idx] - 2 * s * u + s * s * (v - u);
 }
 
 /* accel_em.c:444-541 element updates (projection follows in k_project_*).  Evaluated exactly as the reference's expression
@@ -2455,10 +2518,7 @@ static void dots_enqueue(mchip_context *ctx, const double *uq, const double *vq,
 	double *part_q = ctx->d_redpart, *part_p = ctx->d_redpart + 3 * 512;
 	hipLaunchKernelGGL(k_dots, dim3(gq), dim3(MCHIP_BLOCK), 0, ctx->stream, uq, vq, u2q, (size_t)ctx->nq, mode, part_q, stop);
 	hipLaunchKernelGGL(k_dots, dim3(gp), dim3(MCHIP_BLOCK), 0, ctx->stream, up, vp, u2p, KT, mode, part_p, stop);
-	for (int x = 0; x < nout; x++) {
-		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, part_q + (size_t)x * gq, gq, ctx->d_scalars + 16 + x, stop);
-		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, part_p + (size_t)x * gp, gp, ctx->d_scalars + 20 + x, stop);
-	}
+	hipLaunchKernelGGL(k_reduce_dots, dim3(2 * nout), dim3(MCHIP_BLOCK), 0, ctx->stream, part_q, gq, part_p, gp, nout, ctx->d_scalars, stop);
 }
 
 static int dots_common(mchip_context *ctx, const double *uq, const double *vq, const double *u2q,
@@ -2531,12 +2591,8 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 	/* em_2_steps (em_alg.c:1072-1211): E(A) M(->B) stop, u = B - A; E(B) M(->C) stop, v = C - B */
 	if ((rc = run_estep(ctx, A, B, 1, stop, cyc + 1, true))) return rc;
 	hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_run, ctx->d_scalars, ctx->d_llpart, ctx->ll_parts);
-	hipLaunchKernelGGL(k_diff, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[B], ctx->d_p[A], ctx->d_up[0], KT, stop);
-	hipLaunchKernelGGL(k_diff, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[B], ctx->d_q[A], ctx->d_uq[0], nq, stop);
 	if ((rc = run_estep(ctx, B, C, 1, stop, nullptr, true))) return rc;
 	hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_run, ctx->d_scalars, ctx->d_llpart, ctx->ll_parts);
-	hipLaunchKernelGGL(k_diff, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[C], ctx->d_p[B], ctx->d_vp[0], KT, stop);
-	hipLaunchKernelGGL(k_diff, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[C], ctx->d_q[B], ctx->d_vq[0], nq, stop);
 	/* emll = log_likelihood(findex = C) -> d_scalars[1] (accel_em.c:53).  Admixture model: where the dual individual pass
 	 * exists, emll is taken below, by the pass that visits the extrapolated point (same kernel arithmetic, same bits) */
 	mchip_pass_args dual = pass_args(ctx, B);
@@ -2556,12 +2612,19 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_ll_ind, ctx->d_scalars + 1, stop);
 	}
 	/* step size (accel_em.c:130-243) -> d_scalars[24] */
-	dots_enqueue(ctx, ctx->d_uq[0], ctx->d_vq[0], nullptr, ctx->d_up[0], ctx->d_vp[0], nullptr, 0, 3, stop);
+	{	/* (the secants u = B - A, v = C - B are formed inside the kernels that use them: nothing stores them in a batched cycle) */
+		const int gq = (int)((ctx->nq + 4095) / 4096) > 512 ? 512 : (int)((ctx->nq + 4095) / 4096);
+		const int gp = (int)((KT + 4095) / 4096) > 512 ? 512 : (int)((KT + 4095) / 4096);
+		double *part_q = ctx->d_redpart, *part_p = ctx->d_redpart + 3 * 512;
+		hipLaunchKernelGGL(k_dots_slots, dim3(gq), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_q[A], ctx->d_q[B], ctx->d_q[C], nq, part_q, stop);
+		hipLaunchKernelGGL(k_dots_slots, dim3(gp), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_p[A], ctx->d_p[B], ctx->d_p[C], KT, part_p, stop);
+		hipLaunchKernelGGL(k_reduce_dots, dim3(6), dim3(MCHIP_BLOCK), 0, ctx->stream, part_q, gq, part_p, gp, 3, ctx->d_scalars, stop);
+	}
 	hipLaunchKernelGGL(k_step_size, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars, scheme, cyc, stop);
 	/* accelerated_update (accel_em.c:422-551): B = A - 2 s u + s^2 (v - u) (or A + u + s v), projected; its log likelihood,
 	 * taken by the pass that also leaves the S-side sums -> d_scalars[2] */
-	hipLaunchKernelGGL(k_accel_update, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[A], ctx->d_up[0], ctx->d_vp[0], ctx->d_p[B], KT, 0.0, scheme == 4, ctx->d_scalars + 24, stop);
-	hipLaunchKernelGGL(k_accel_update, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[A], ctx->d_uq[0], ctx->d_vq[0], ctx->d_q[B], nq, 0.0, scheme == 4, ctx->d_scalars + 24, stop);
+	hipLaunchKernelGGL(k_accel_update_slots, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[A], ctx->d_p[B], ctx->d_p[C], ctx->d_p[B], KT, scheme == 4, ctx->d_scalars + 24, stop);
+	hipLaunchKernelGGL(k_accel_update_slots, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[A], ctx->d_q[B], ctx->d_q[C], ctx->d_q[B], nq, scheme == 4, ctx->d_scalars + 24, stop);
 	if ((rc = project_slot(ctx, B, stop))) return rc;
 	if (!ctx->admixture) {
 		if ((rc = run_mixture(ctx, B, B, 0, 1, stop, 2))) return rc;	/* nothing of this pass serves the next E step */
