@@ -6,6 +6,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PROF_KINDS = 4
+ABI_VERSION = 2          # MCHIP_ABI_VERSION of include/multiclust_hip.h these bindings were written against
 STATUS = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "ALLOC", 5: "STATE", 6: "UNSUPPORTED"}
 
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_device_count():
     lib = mc.load()
-    assert lib.mchip_abi_version() == 2
+    assert lib.mchip_abi_version() == hip.ABI_VERSION == 2
     n = C.c_int(-1)
     assert lib.mchip_device_count(C.byref(n)) == 0
     assert n.value >= 0
@@ -43,3 +43,13 @@ def test_no_gpu_fails_loudly():
         pytest.skip("a GPU is present")
     with pytest.raises(mc.HipError):
         mc.Context(0)
+
+
+def test_header_bindings_and_build_entry_agree_on_the_abi_version():
+    """MCHIP_ABI_VERSION of the header = the version the Python bindings were written against = what __graft_entry__.build()
+    checks after building (a bump of one without the others would fail the driver's build step)."""
+    src = open(os.path.join(ROOT, "include", "multiclust_hip.h")).read()
+    m = re.search(r"#define\s+MCHIP_ABI_VERSION\s+(\d+)", src)
+    assert m and int(m.group(1)) == hip.ABI_VERSION
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "hip.ABI_VERSION" in entry
