@@ -117,18 +117,28 @@ class Env:
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         self.dist = None
-        if self.world > 1:
+        # MC_BENCH_FORCE_PG=1: a one-rank run still creates the process group and sends its exchanges through it, so that
+        # torch's RCCL initialisation, all_reduce and barrier on this image have run on a one-GPU box (tests/test_gpu_bench.py)
+        # before the driver's first N > 1 launch depends on them
+        force_pg = self.world == 1 and os.environ.get("MC_BENCH_FORCE_PG") == "1"
+        if self.world > 1 or force_pg:
             import torch.distributed as dist
+            if force_pg and "MASTER_ADDR" not in os.environ:
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]), RANK="0", WORLD_SIZE="1")
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=self.dev)
             else:
                 dist.init_process_group(self.backend)
             self.dist = dist
         self.cdev = self.dev if self.backend == "nccl" else torch.device("cpu")      # where the collective's tensors live
+        self.collectives = 0          # all-reduces and barriers that went through the process group (reported on the line)
 
     def barrier(self, ctx=None):
         if self.dist is not None:
             self.dist.barrier()
+            self.collectives += 1
         self.torch.cuda.synchronize()
         if ctx is not None:
             from multiclust_amd import hip
@@ -138,7 +148,23 @@ class Env:
         t = self.torch.tensor(values, dtype=self.torch.float64, device=self.cdev)
         if self.dist is not None:
             self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+            self.collectives += 1
         return t.cpu().tolist()
+
+    def same_everywhere(self, what, *arrays):
+        """Every rank generates the data set itself (gen_dataset on its own device).  The units of c4 / c5 are fits of ONE data
+        set: before anything is timed, all-reduce MIN and MAX of a checksum of it and stop the job if two ranks disagree --
+        otherwise the per-unit table would still complete, on different data.  Returns the checksum."""
+        import zlib
+        crc = [float(zlib.crc32(memoryview(np.ascontiguousarray(a)).cast("B"))) for a in arrays]      # 32-bit: exact in a double
+        lo, hi = self.reduce(crc, "MIN"), self.reduce(crc, "MAX")
+        if lo != hi or lo != crc:
+            sys.stderr.write("bench.py: rank %d: %s differs between ranks (checksums %s, min %s, max %s)\n" % (self.rank, what, crc, lo, hi))
+            sys.stderr.flush()
+            if self.dist is not None:
+                self.dist.barrier()
+            sys.exit(4)
+        return [int(c) for c in crc]
 
     def close(self):
         if self.dist is not None:
@@ -182,7 +208,11 @@ def gen_dataset(I, L, K, ploidy, maxal, seed, device):
 
 
 def workload_data(w, env):
-    return gen_dataset(w["I"], w["L"], w["K"], w["ploidy"], w["maxal"], 20250117 + w["dseed"], env.dev)
+    ua, geno = gen_dataset(w["I"], w["L"], w["K"], w["ploidy"], w["maxal"], 20250117 + w["dseed"], env.dev)
+    if os.environ.get("MC_BENCH_CORRUPT_RANK") == str(env.rank):      # test knob: this rank's data set differs in one byte
+        geno[0, 0, 0] ^= 1
+    w["data_crc32"] = env.same_everywhere("the synthetic data set", ua, geno) if env.dist is not None else None
+    return ua, geno
 
 
 def algorithmic_bytes(w, T, K=None):
@@ -471,6 +501,7 @@ def run_units(env, fit, w, T, n_units, cycles, warmup, with_roofline=True):
             raise SystemExit("unit %d: fatal=%d" % (u, r.fatal))
         local.append(r)
     results = shard.exchange(local, n_units, env.dist, env.cdev)      # the path's one exchange (all-reduce of disjoint rows)
+    env.collectives += env.dist is not None
     env.barrier(ctx)
     dt = time.perf_counter() - t0
     dt = env.reduce([dt], "MAX")[0]
@@ -582,14 +613,36 @@ def run_bootstrap(env, w, ua, geno, n_rep, budget, n_init=1, n_streams=1):
 
 
 # ------------------------------------------------------------------------------------------------ main
+_REAL_STDOUT = None
+
+
+def keep_stdout_for_the_result_line():
+    """stdout carries ONE JSON line.  Libraries write there too (RCCL prints a five-line version banner on stdout when torch
+    creates the first communicator -- seen on the GPU box with world size 1), so a rank's file descriptor 1 points at stderr
+    from here on and the result line goes to the descriptor saved here."""
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(text):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (text + "\n").encode())
+
+
 def finish(env, args, out, scaling):
     line = {"metric": "EM iterations/sec, IxLxK admixture", "value": out["value"], "unit": "EM iterations/s", "n_gpus": env.world,
             "steps": out["steps"], "warmup": args.warmup, "ms_per_step": out["ms_per_step"], "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": out["config"]}
+    # what the exchanges of this run went through: "none" (one rank, nothing to exchange), else the torch.distributed backend
+    # (nccl = RCCL), the collectives issued on it and the data-set checksum every rank agreed on before the timed region
+    line["exchange"] = {"backend": env.backend if env.dist is not None else "none", "collectives": env.collectives,
+                        "data_crc32_all_ranks": WORKLOADS[args.workload].get("data_crc32")}
     for k in ("roofline", "cpu_baseline", "secondary"):
         if k in out:
             line[k] = out[k]
-    print(json.dumps(line), flush=True)
+    emit(json.dumps(line))
 
 
 def main():
@@ -617,6 +670,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         launch_ranks(args.gpus)                        # does not return
 
+    keep_stdout_for_the_result_line()
     env = Env(args.gpus)
     name = args.workload
     w = WORKLOADS[name]

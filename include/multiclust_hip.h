@@ -238,6 +238,10 @@ int mchip_comm_create(mchip_comm **comm, int n_devices, const int *devices);
 int mchip_comm_all_reduce(mchip_comm *comm, double *const *host_bufs, int count, int op);
 int mchip_comm_destroy(mchip_comm *comm);
 const char *mchip_comm_last_error(const mchip_comm *comm);
+/* what the communicator is and has done: devices it spans, the version of the RCCL it loaded (ncclGetVersion's code, 0 when the
+ * library does not say) and the all-reduces completed on it -- the evidence a caller (or a test) has that the exchange went
+ * through RCCL.  Any of the three pointers may be NULL. */
+int mchip_comm_info(const mchip_comm *comm, int *n_devices, int *rccl_version, unsigned long long *n_reductions);
 
 /* ---- measurement hooks (bench.py): HIP events on the context's own stream ---- */
 int mchip_profile_begin(mchip_context *ctx);

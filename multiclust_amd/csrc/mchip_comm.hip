@@ -29,6 +29,8 @@ struct mchip_comm {
 	ncclResult_t (*GroupStart)(void);
 	ncclResult_t (*GroupEnd)(void);
 	const char *(*GetErrorString)(ncclResult_t);
+	ncclResult_t (*GetVersion)(int *);	/* optional */
+	unsigned long long n_reductions;	/* all-reduces completed on this communicator */
 	char err[512];
 };
 
@@ -68,6 +70,8 @@ int mchip_comm_create(mchip_comm **out, int n_devices, const int *devices)
 	*(void **)&c->GroupStart = dlsym(c->dl, "ncclGroupStart");
 	*(void **)&c->GroupEnd = dlsym(c->dl, "ncclGroupEnd");
 	*(void **)&c->GetErrorString = dlsym(c->dl, "ncclGetErrorString");
+	*(void **)&c->GetVersion = dlsym(c->dl, "ncclGetVersion");
+	c->n_reductions = 0;
 	if (!c->CommInitAll || !c->CommDestroy || !c->AllReduce || !c->GroupStart || !c->GroupEnd || !c->GetErrorString) {
 		fprintf(stderr, "mchip_comm_create: RCCL symbols missing\n");
 		dlclose(c->dl);
@@ -130,6 +134,20 @@ int mchip_comm_all_reduce(mchip_comm *c, double *const *host_bufs, int count, in
 		    hipStreamSynchronize(c->streams[d]) != hipSuccess)
 			return cfail(c, MCHIP_ERR_HIP, "download", "");
 	}
+	c->n_reductions++;
+	return MCHIP_OK;
+}
+
+int mchip_comm_info(const mchip_comm *c, int *n_devices, int *rccl_version, unsigned long long *n_reductions)
+{
+	if (!c) return MCHIP_ERR_INVALID;
+	if (n_devices) *n_devices = c->n;
+	if (rccl_version) {
+		int v = 0;
+		if (!c->GetVersion || c->GetVersion(&v) != ncclSuccess) v = 0;
+		*rccl_version = v;
+	}
+	if (n_reductions) *n_reductions = c->n_reductions;
 	return MCHIP_OK;
 }
 

@@ -240,6 +240,23 @@ static int get_comm(const mc_cli_options *o, run_state *st, mchip_comm **out)
 	return rc;
 }
 
+/* the run's one exchange: RCCL all-reduce (sum) of the per-unit table; MC_TRACE_EXCHANGE=1 reports on stderr what
+ * the communicator is and has done (tests/test_gpu_cli.py reads it: the one-GPU rehearsal has to go through RCCL, not past it) */
+static int exchange_table(const mc_cli_options *o, run_state *st, double **tab, int count, const char *what)
+{
+	mchip_comm *comm = NULL;
+	int rc = get_comm(o, st, &comm);
+	if (rc) return rc;
+	if ((rc = mchip_comm_all_reduce(comm, tab, count, 0))) { fprintf(stderr, "ERROR [mc_main.c]: %s\n", mchip_comm_last_error(comm)); return rc; }
+	if (getenv("MC_TRACE_EXCHANGE")) {
+		int n = 0, ver = 0;
+		unsigned long long done = 0;
+		mchip_comm_info(comm, &n, &ver, &done);
+		fprintf(stderr, "exchange: RCCL %d all-reduce #%llu, %d doubles (%s) over %d device(s)\n", ver, done, count, what, n);
+	}
+	return 0;
+}
+
 static void print_model_state(const mc_cli_options *o, const mc_cli_data *d, const run_state *st, int K, int diff, int newline)
 {
 	char ab[16];
@@ -443,7 +460,6 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 	mc_unit_result *res = calloc((size_t)n_units, sizeof *res);
 	double **tab = calloc((size_t)n_gpus, sizeof *tab);
 	int *count_K = calloc((size_t)K, sizeof *count_K), rc = 0;
-	mchip_comm *comm = NULL;
 	if (!w || !th || !res || !tab || !count_K) { rc = MCHIP_ERR_ALLOC; goto DONE; }
 	for (int x = 0; x < n_dev; x++) {
 		w[x].o = o; w[x].d = d; w[x].md = md; w[x].K = K; w[x].index = x; w[x].n_dev = n_dev; w[x].n_units = n_units;
@@ -466,10 +482,7 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 		row[0] = res[u].logL; row[1] = res[u].converged; row[2] = res[u].n_iter; row[3] = res[u].time_stop;
 		row[4] = res[u].iter_stop; row[5] = res[u].pindex; row[6] = res[u].fatal; row[7] = res[u].seconds_run; row[8] = 1.0;
 	}
-	if (exchange_needed(o)) {
-		if ((rc = get_comm(o, st, &comm))) goto DONE;
-		if ((rc = mchip_comm_all_reduce(comm, tab, n_units * RES_FIELDS, 0))) { fprintf(stderr, "ERROR [mc_main.c]: %s\n", mchip_comm_last_error(comm)); goto DONE; }
-	}
+	if (exchange_needed(o) && (rc = exchange_table(o, st, tab, n_units * RES_FIELDS, "per-initialisation results"))) goto DONE;
 	for (int x = 1; x < n_gpus; x++)
 		if (memcmp(tab[0], tab[x], sizeof(double) * (size_t)n_units * RES_FIELDS)) { fprintf(stderr, "ERROR [mc_main.c]: devices disagree after the all-reduce\n"); rc = MCHIP_ERR_STATE; goto DONE; }
 
@@ -631,7 +644,6 @@ static int run_bootstrap_sharded(const mc_cli_options *o, const mc_cli_data *d, 
 	double *ts = calloc((size_t)B, sizeof *ts), **tab = calloc((size_t)n_gpus, sizeof *tab);
 	char **text = calloc((size_t)B, sizeof *text);
 	int rc = 0, ntime = 0;
-	mchip_comm *comm = NULL;
 	if (!w || !th || !ts || !tab || !text) { rc = MCHIP_ERR_ALLOC; goto DONE; }
 	for (int x = 0; x < n_dev; x++) {
 		w[x].o = o; w[x].d = d; w[x].md = md; w[x].st = st; w[x].index = x; w[x].n_dev = n_dev;
@@ -651,10 +663,7 @@ static int run_bootstrap_sharded(const mc_cli_options *o, const mc_cli_data *d, 
 		row[0] = ts[b];
 		row[1] = 1.0;
 	}
-	if (exchange_needed(o)) {
-		if ((rc = get_comm(o, st, &comm))) goto DONE;
-		if ((rc = mchip_comm_all_reduce(comm, tab, B * 2, 0))) { fprintf(stderr, "ERROR [mc_main.c]: %s\n", mchip_comm_last_error(comm)); goto DONE; }
-	}
+	if (exchange_needed(o) && (rc = exchange_table(o, st, tab, B * 2, "bootstrap test statistics"))) goto DONE;
 	for (int b = 0; b < B; b++) {
 		if (tab[0][2 * b + 1] != 1.0) { fprintf(stderr, "ERROR [mc_main.c]: bootstrap replicate %d was fitted %g times\n", b, tab[0][2 * b + 1]); rc = MCHIP_ERR_STATE; goto DONE; }
 		st->ts_bs = tab[0][2 * b];

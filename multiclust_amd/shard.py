@@ -28,7 +28,7 @@ def exchange(local_results, n_units, dist=None, device="cpu"):
     for r in local_results:
         t[r.unit] = torch.tensor([r.logL, r.converged, r.n_iter, r.time_stop, r.iter_stop, r.pindex, r.fatal, 1.0],
                                  dtype=torch.float64)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():    # also with one rank: the rehearsal of the exchange on a one-GPU box
         dist.all_reduce(t, op=dist.ReduceOp.SUM)      # rows are disjoint across ranks
     rows = t.cpu().tolist()
     out = []

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 
 class OneRank:
     """bench.Env for a single rank without a process group"""
-    world, rank, local_rank, dist, cdev = 1, 0, 0, None, "cpu"
+    world, rank, local_rank, dist, cdev, collectives = 1, 0, 0, None, "cpu", 0
 
     def barrier(self, ctx=None):
         pass
@@ -71,11 +71,13 @@ def test_c5_replicates_agree_with_command_line(tmp_path):
         assert abs(bs - got) <= 2e-6, (bs, got)
 
 
-def run_bench(args, env_extra, timeout=900):
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+def run_bench(args, env_extra, timeout=900, expect_failure=False):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=timeout)
+    if expect_failure:
+        return res
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.split("\n") if l.strip()]
     assert len(lines) == 1, res.stdout                       # exactly one JSON line on stdout
@@ -99,3 +101,31 @@ def test_two_ranks_give_the_one_rank_results(workload):
     else:
         assert c2["replicates"] == 5 and c2["em_iterations"] == 5 * 2 * 7
         assert c1["ts_first"] == c2["ts_first"] and c1["ts_obs"] == c2["ts_obs"] and c1["p_value"] == c2["p_value"]
+    assert two["exchange"]["backend"] == "gloo" and two["exchange"]["collectives"] >= 4
+    crc = two["exchange"]["data_crc32_all_ranks"]
+    assert len(crc) == 2 and all(isinstance(c, int) for c in crc)       # allele counts and genotype: the same on both ranks
+    assert one["exchange"] == {"backend": "none", "collectives": 0, "data_crc32_all_ranks": None}
+
+
+@pytest.mark.parametrize("workload", ["c4s", "c5s", "c1"])
+def test_one_rank_through_the_rccl_process_group(workload):
+    """MC_BENCH_FORCE_PG=1: one rank, but the process group exists (backend nccl = RCCL, initialised on this device exactly as
+    the driver's N > 1 launch initialises it) and the data-set check, the barriers and the run's exchange (all-reduce of the
+    per-unit table / the test statistics / the best log likelihood) go through it.  Results are those of the run without it."""
+    args = ["--workload", workload, "--no-cpu-baseline", "--no-secondary", "--steps", "6", "--units", "5", "--replicates", "4", "--settle", "0"]
+    plain = run_bench(args, {})
+    pg = run_bench(args, {"MC_BENCH_FORCE_PG": "1"})
+    assert pg["n_gpus"] == 1 and pg["exchange"]["backend"] == "nccl" and pg["exchange"]["collectives"] >= 6
+    assert len(pg["exchange"]["data_crc32_all_ranks"]) == 2
+    for key in ("unit_logL", "best_logL", "ts_first", "ts_obs", "em_iterations"):
+        if key in plain["config"]:
+            assert plain["config"][key] == pg["config"][key], key
+
+
+def test_ranks_with_different_data_sets_stop_before_the_timed_region():
+    """every rank generates the synthetic data set on its own device; if two devices' generators ever disagreed the units of c4
+    would be fits of different data.  One byte changed on rank 1: both ranks leave with an error, no JSON line."""
+    res = run_bench(["--workload", "c4s", "--no-cpu-baseline", "--steps", "2", "--units", "4", "--gpus", "2"],
+                    {"MC_BENCH_DEVICE": "0", "MC_BENCH_BACKEND": "gloo", "MC_BENCH_CORRUPT_RANK": "1"}, expect_failure=True)
+    assert res.returncode != 0 and '{"metric"' not in res.stdout
+    assert "the synthetic data set differs between ranks" in res.stderr

@@ -25,6 +25,7 @@ def run_cli(case, tmp_path, extra=()):
     cmd = [BIN, "-f", stru, "-d", str(tmp_path)] + rest + list(extra)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
+    run_cli.last_stderr = res.stderr
     return gdir, CLOCK.sub("HH:MM:SS", res.stdout.replace(stru, os.path.basename(stru)))
 
 
@@ -125,9 +126,16 @@ def test_cli_bootstrap_device_host_and_sharded_agree(tmp_path, monkeypatch):
             monkeypatch.setenv("MC_HOST_BOOTSTRAP", "1")
         if mode == "sharded":
             monkeypatch.setenv("MC_FORCE_SHARDED", "1")
+            monkeypatch.setenv("MC_TRACE_EXCHANGE", "1")
             extra = ["--gpus", "1"]
         res = subprocess.run(cmd + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert res.returncode == 0, res.stderr
+        if mode == "sharded":
+            # H0 and HA fits of the observed data (one all-reduce each), then the replicates' test statistics: one communicator,
+            # three exchanges through RCCL
+            trace = [l for l in res.stderr.split("\n") if l.startswith("exchange: RCCL")]
+            assert [t.split("#")[1].split(",")[0] for t in trace] == ["1", "2", "3"], res.stderr
+            assert "bootstrap test statistics" in trace[2] and "6 doubles" in trace[2]
         assert res.stdout.count("Bootstrap dataset") == 3 and "p-value to reject H0: K=2" in res.stdout
         text = CLOCK.sub("HH:MM:SS", res.stdout)
         outs.append(text[text.index("Bootstrap dataset 1"):])
@@ -141,8 +149,13 @@ def test_cli_sharded_path_on_one_gpu_reproduces_serial_reference(case, streams, 
     result table, serial-order bookkeeping replay, winner's owner writes the files) rehearsed with one device:
     stdout and files must equal the reference's serial run."""
     monkeypatch.setenv("MC_FORCE_SHARDED", "1")
+    monkeypatch.setenv("MC_TRACE_EXCHANGE", "1")
     # streams > 1: several workers (host thread + context + stream each) share the one GPU
     gdir, out = run_cli(case, tmp_path, extra=["--gpus", "1", "--streams", str(streams)])
+    # the exchange really went through get_comm() -> ncclCommInitAll -> mchip_comm_all_reduce (one per K fitted), not past it
+    trace = [l for l in run_cli.last_stderr.split("\n") if l.startswith("exchange: RCCL")]
+    assert len(trace) == 1 and "all-reduce #1" in trace[0] and "over 1 device(s)" in trace[0], run_cli.last_stderr
+    assert int(trace[0].split()[2]) >= 20000 and "per-initialisation results" in trace[0]
     ref_lines = CLOCK.sub("HH:MM:SS", open(os.path.join(gdir, "stdout.txt")).read()).strip().split("\n")
     got_lines = out.strip().split("\n")
     assert len(ref_lines) == len(got_lines), out
