@@ -14,9 +14,12 @@ BIN  = multiclust_amd/bin
 
 all: $(LIB)/libmulticlust_hip.so $(LIB)/libmulticlust_host.so $(BIN)/multiclust oracle
 
-# -amdgpu-spill-vgpr-to-agpr=false: with ROCm 7.2's hipcc the kernels that use the whole register file and spill some of it
-# to accumulation registers can come out wrong (k_individual_sparse<4,true,true,false> at K = 52 returned -inf / NaN log
-# likelihoods; found by a fuzz soak, gone with spills to scratch).  Only K > 20 spills at all; K <= 20 is unaffected.
+# -amdgpu-spill-vgpr-to-agpr=false: ROCm 7.2's hipcc loses a lane when it reloads a multi-dword VGPR tuple whose spill was split
+# between AGPRs and scratch (fewer free AGPRs than lanes).  Shown in profiles/r03_k52_spill.md on the one-lane K = 52 instance of
+# k_individual_sparse<4,true,true,false>: gn.g0 = v[0:3] goes to a253, a254, a255 + scratch; a[128:131] gets three lanes back,
+# a129 <- a255 is never emitted, and every block after a chunk's first gathers rows from garbage allele indices (-inf / NaN).
+# With the flag tuples spill to scratch whole.  Only kernels that use the whole register file spill (K > 20); applied to every
+# translation unit all the same.  Reproducer: `make exp-k52`, scripts/diag/k52_spill.sh.
 KFLAGS = -mllvm -amdgpu-spill-vgpr-to-agpr=false
 $(OBJ)/mchip_k%.o: multiclust_amd/csrc/mchip_kernels_k.hip multiclust_amd/csrc/mchip_internal.h include/multiclust_hip.h
 	@mkdir -p $(OBJ)
@@ -24,11 +27,11 @@ $(OBJ)/mchip_k%.o: multiclust_amd/csrc/mchip_kernels_k.hip multiclust_amd/csrc/m
 
 $(OBJ)/mchip.o: multiclust_amd/csrc/mchip.hip multiclust_amd/csrc/mchip_internal.h include/multiclust_hip.h
 	@mkdir -p $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -c $< -o $@
 
 $(OBJ)/mchip_comm.o: multiclust_amd/csrc/mchip_comm.hip include/multiclust_hip.h
 	@mkdir -p $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -c $< -o $@
 
 $(LIB)/libmulticlust_hip.so: $(OBJ)/mchip.o $(OBJ)/mchip_comm.o $(KOBJ)
 	@mkdir -p $(LIB)
@@ -60,8 +63,19 @@ exp-scatter: $(LIB)/libmulticlust_hip.so
 	$(HIPCC) --offload-arch=$(ARCH) --offload-compress -shared -fPIC -o scripts/exp/libmulticlust_hip_scatter.so \
 		$(filter-out $(OBJ)/mchip_k8.o,$(OBJ)/mchip.o $(OBJ)/mchip_comm.o $(KOBJ)) build/exp/mchip_k8.o -ldl
 
+# diagnosis behind profiles/r03_k52_spill.md: the K = 52 kernels with one lane per individual (MCHIP_FORCE_SPLIT1: the instance
+# that returned -inf / NaN before the lane split) built with hipcc's default VGPR->AGPR spilling and with KFLAGS, each linked
+# with a matching mchip.o into a library of its own; scripts/diag/k52_spill.sh runs both through MCHIP_LIB_PATH
+exp-k52: $(LIB)/libmulticlust_hip.so
+	@mkdir -p build/exp scripts/exp
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -DMCHIP_FORCE_SPLIT1 -c multiclust_amd/csrc/mchip.hip -o build/exp/mchip_split1.o
+	$(HIPCC) $(HIPFLAGS) -DMCHIP_FORCE_SPLIT1 -DMCHIP_K=52 -c multiclust_amd/csrc/mchip_kernels_k.hip -o build/exp/mchip_k52_agpr.o
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -DMCHIP_FORCE_SPLIT1 -DMCHIP_K=52 -c multiclust_amd/csrc/mchip_kernels_k.hip -o build/exp/mchip_k52_scratch.o
+	for v in agpr scratch; do $(HIPCC) --offload-arch=$(ARCH) --offload-compress -shared -fPIC -o scripts/exp/libmulticlust_hip_k52$$v.so \
+		build/exp/mchip_split1.o $(OBJ)/mchip_comm.o $(filter-out $(OBJ)/mchip_k52.o,$(KOBJ)) build/exp/mchip_k52_$$v.o -ldl; done
+
 clean:
 	rm -rf build $(LIB)/*.so $(BIN) scripts/micro/fp64_micro scripts/micro/op_cost scripts/exp/*.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle micro exp-scatter clean
+.PHONY: all oracle micro exp-scatter exp-k52 clean

@@ -30,10 +30,20 @@
 /* Sparse individual pass: lanes that share one individual, each holding a range of k (its part of q, of the S-side sums and of
  * every gathered P row; the partial dot products are combined across the lanes).  One lane holds 4K doubles: above K = 27 that
  * leaves one or two waves per SIMD (292 registers at K = 32), above 32 it spills. */
+#ifdef MCHIP_FORCE_SPLIT1
+/* DIAGNOSTIC builds only (scripts/diag/k52_spill.sh): one lane per individual at every K, the form in which the K = 52 instance
+ * of the tetraploid reciprocal-per-copy pass gave wrong results with hipcc's VGPR-to-AGPR spilling (profiles/r03_k52_spill.md) */
+constexpr int mchip_ind_split(int) { return 1; }
+#else
 constexpr int mchip_ind_split(int K) { return K <= 27 ? 1 : (K <= 48 ? 2 : 4); }
+#endif
 /* lanes per workgroup of the individual-side kernels: the staged P tile of a workgroup grows with K (34 KB at K = 64), so the
  * largest K share it among four waves instead of two, or LDS capacity would leave two waves per SIMD */
+#ifdef MCHIP_FORCE_SPLIT1
+constexpr int mchip_qblock(int) { return MCHIP_QBLOCK; }
+#else
 constexpr int mchip_qblock(int K) { return K > 48 ? 2 * MCHIP_QBLOCK : MCHIP_QBLOCK; }
+#endif
 /* LDS row stride of the staged P tiles in doubles: rows stay 16-byte aligned and hold the lanes' k ranges (each padded to an even
  * count); a stride of 128 or 256 bytes would put the rows of a locus on the same banks (64 banks x 4 bytes), so multiples of 16
  * get two doubles of padding */
