@@ -51,7 +51,7 @@ oracle: $(LIB)/libmulticlust_host.so
 	$(MAKE) -C oracle all
 
 # microbenchmarks behind profiles/r01_fp64_microbench.txt and r01_op_cost_microbench.txt (run on the GPU box; binaries are not tracked)
-micro: scripts/micro/fp64_micro scripts/micro/op_cost
+micro: scripts/micro/fp64_micro scripts/micro/op_cost scripts/micro/lds_valu
 scripts/micro/%: scripts/micro/%.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 
@@ -74,8 +74,18 @@ exp-k52: $(LIB)/libmulticlust_hip.so
 	for v in agpr scratch; do $(HIPCC) --offload-arch=$(ARCH) --offload-compress -shared -fPIC -o scripts/exp/libmulticlust_hip_k52$$v.so \
 		build/exp/mchip_split1.o $(OBJ)/mchip_comm.o $(filter-out $(OBJ)/mchip_k52.o,$(KOBJ)) build/exp/mchip_k52_$$v.o -ldl; done
 
+# A/B builds of the K = 8 kernels: `make exp-k8 EXPNAME=w5 EXPFLAGS=-DMCHIP_SPARSE_WAVES=5` -> scripts/exp/libmulticlust_hip_w5.so
+# (the K = 8 object rebuilt with EXPFLAGS, everything else the product's); scripts/diag/ab.sh times variants against the shipped
+# library in alternation on one box
+EXPNAME ?= exp
+exp-k8: $(LIB)/libmulticlust_hip.so
+	@mkdir -p build/exp scripts/exp
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) $(EXPFLAGS) -DMCHIP_K=8 -c multiclust_amd/csrc/mchip_kernels_k.hip -o build/exp/mchip_k8_$(EXPNAME).o
+	$(HIPCC) --offload-arch=$(ARCH) --offload-compress -shared -fPIC -o scripts/exp/libmulticlust_hip_$(EXPNAME).so \
+		$(filter-out $(OBJ)/mchip_k8.o,$(OBJ)/mchip.o $(OBJ)/mchip_comm.o $(KOBJ)) build/exp/mchip_k8_$(EXPNAME).o -ldl
+
 clean:
-	rm -rf build $(LIB)/*.so $(BIN) scripts/micro/fp64_micro scripts/micro/op_cost scripts/exp/*.so
+	rm -rf build $(LIB)/*.so $(BIN) scripts/micro/fp64_micro scripts/micro/op_cost scripts/micro/lds_valu scripts/exp/*.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle micro exp-scatter exp-k52 clean
+.PHONY: all oracle micro exp-scatter exp-k52 exp-k8 clean
