@@ -1443,7 +1443,7 @@ static int set_shape_impl(mchip_context *ctx, int I, int L, int ploidy, const in
 	free_model(ctx);	/* workspaces depend on T */
 	free_data(ctx);
 
-	std::vector<int32_t> toff(L + 9);	/* padded: kernels read 8 offsets per locus block */
+	std::vector<int32_t> toff(L + 25);	/* padded: kernels read the offsets of a block of 8 loci and of the two blocks behind it */
 	toff[0] = 0;
 	int maxM = 0, minM = 1 << 30;
 	for (int l = 0; l < L; l++) {
@@ -1454,7 +1454,7 @@ static int set_shape_impl(mchip_context *ctx, int I, int L, int ploidy, const in
 		if (ua[l] > maxM) maxM = ua[l];
 	}
 	const int T = toff[L];
-	for (int x = L + 1; x < L + 9; x++) toff[x] = T;
+	for (int x = L + 1; x < L + 25; x++) toff[x] = T;
 	if (T <= 0) return fail(ctx, MCHIP_ERR_INVALID, "no alleles%s", nullptr);
 	std::vector<int32_t> col_locus(T);
 	std::vector<uint8_t> col_allele(T);
@@ -1468,13 +1468,13 @@ static int set_shape_impl(mchip_context *ctx, int I, int L, int ploidy, const in
 	ctx->geno_bytes_A = (size_t)((I + 7) / 8) * L * 8 * ploidy;
 	ctx->geno_bytes_S = (size_t)((L + 7) / 8) * I * 8 * ploidy;
 	HIPCHK(hipMalloc((void **)&ctx->d_ua, sizeof(int32_t) * L));
-	HIPCHK(hipMalloc((void **)&ctx->d_toff, sizeof(int32_t) * (L + 9)));
+	HIPCHK(hipMalloc((void **)&ctx->d_toff, sizeof(int32_t) * (L + 25)));
 	HIPCHK(hipMalloc((void **)&ctx->d_col_locus, sizeof(int32_t) * T));
 	HIPCHK(hipMalloc((void **)&ctx->d_col_allele, T));
 	HIPCHK(hipMalloc((void **)&ctx->d_gtA, ctx->geno_bytes_A));
 	HIPCHK(hipMalloc((void **)&ctx->d_gtS, ctx->geno_bytes_S));
 	HIPCHK(hipMemcpyAsync(ctx->d_ua, ua, sizeof(int32_t) * L, hipMemcpyHostToDevice, ctx->stream));
-	HIPCHK(hipMemcpyAsync(ctx->d_toff, toff.data(), sizeof(int32_t) * (L + 9), hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipMemcpyAsync(ctx->d_toff, toff.data(), sizeof(int32_t) * (L + 25), hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(ctx->d_col_locus, col_locus.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(ctx->d_col_allele, col_allele.data(), T, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));	/* the host vectors go out of scope */

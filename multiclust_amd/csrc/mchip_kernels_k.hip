@@ -472,9 +472,16 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 	constexpr int STAGE = 2;
 	const bool staged = a.tile_cols * K <= STAGE * QBLOCK;	/* wave-uniform */
 
+	/* column offsets of the current block's and the next block's loci: E[x] = toff[8 lb + x], x = 0..16 (toff is padded by 24
+	 * entries equal to T).  Its upper half for the NEXT block is requested at the head of this one and moved in at its end: the
+	 * head of a block -- right behind the workgroup barrier, where the waves of a workgroup all stand at the same place -- then
+	 * starts its prefetches at once instead of behind three dependent scalar loads (c_lo, then n_lo, then n_hi) */
+	int E[17];
+#pragma unroll
+	for (int x = 0; x < 17; x++) E[x] = a.toff[lb0 * 8 + x];
 	/* stage the first tile */
 	{
-		const int c_lo = a.toff[lb0 * 8], c_hi = a.toff[min(lb0 * 8 + 8, a.L)];
+		const int c_lo = E[0], c_hi = E[8];
 		const int nel = (c_hi - c_lo) * K;
 		for (int x = threadIdx.x; x < nel; x += QBLOCK) {
 			lds[(x / K) * KP + (x % K)] = a.P[(size_t)c_lo * K + x];
@@ -488,7 +495,10 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 		const int buf = (lb - lb0) & 1;
 		const double *tile = lds + (size_t)buf * a.tile_cols * KP;
 		const double *tile2 = lds2 + (size_t)buf * a.tile_cols * KP;
-		const int c_lo = a.toff[lb * 8];
+		const int c_lo = E[0];
+		int En[8];
+#pragma unroll
+		for (int x = 0; x < 8; x++) En[x] = a.toff[(lb + 1) * 8 + 9 + x];
 		/* prefetch the next tile and the next genotype group.  Tiles of up to STAGE * QBLOCK doubles (every data set with
 		 * <= 4 alleles per locus at K <= 8) wait in registers while this block is computed and go to the other LDS buffer
 		 * after it, so no s_waitcnt for them sits in front of the arithmetic; larger tiles are copied through at once */
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 		double *dst = lds + (size_t)(buf ^ 1) * a.tile_cols * KP;
 		double *dst2 = lds2 + (size_t)(buf ^ 1) * a.tile_cols * KP;
 		if (lb + 1 < lb_end) {
-			const int n_lo = a.toff[(lb + 1) * 8], n_hi = a.toff[min((lb + 1) * 8 + 8, a.L)];
+			const int n_lo = E[8], n_hi = E[16];
 			nel_next = (n_hi - n_lo) * K;
 			const double *src = a.P + (size_t)n_lo * K;
 			const double *src2 = DUAL ? a.P2 + (size_t)n_lo * K : nullptr;
@@ -516,11 +526,9 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 			}
 		}
 		gn.load(a.gtS, (size_t)min(lb + 1, lb_end - 1) * a.I + i, pl);
-		/* the block's eight locus offsets in one scalar load (toff is padded by 8 entries), instead of one s_load + wait
-		 * at the head of every locus */
 		int tb[8];
 #pragma unroll
-		for (int j = 0; j < 8; j++) tb[j] = a.toff[lb * 8 + j];
+		for (int j = 0; j < 8; j++) tb[j] = E[j];
 		/* one locus: all of its copies; a lambda so that full blocks run as straight-line code (no per-locus bound check:
 		 * the scheduler can then start the next locus's LDS reads under this locus's arithmetic) */
 		auto one_locus = [&](int j) __attribute__((always_inline)) {
@@ -677,6 +685,10 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 			}
 		}
 		g = gn;
+#pragma unroll
+		for (int x = 0; x <= 8; x++) E[x] = E[x + 8];
+#pragma unroll
+		for (int x = 0; x < 8; x++) E[9 + x] = En[x];
 		__syncthreads();	/* next tile is complete and this one may be overwritten */
 	}
 	const double ll = (double)ex * 0.693147180559945309417 + log(prod);

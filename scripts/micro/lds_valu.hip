@@ -12,7 +12,7 @@
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 template <int NF, int R, bool B64>
-__global__ __launch_bounds__(128) void k_mix(double *out, int iters)
+__global__ __launch_bounds__(128) void k_mix(double *out, int iters, unsigned long long *clk)
 {
 	__shared__ __attribute__((aligned(16))) double tile[32 * 8 * 2];	// 32 rows of 64 bytes, as a P tile of 8 loci x 4 alleles at K = 8
 	for (int x = threadIdx.x; x < 32 * 8 * 2; x += 128) tile[x] = 1e-3 * x;
@@ -23,6 +23,8 @@ __global__ __launch_bounds__(128) void k_mix(double *out, int iters)
 	const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)(const char *)tile + (threadIdx.x % 4) * 64;
 	v2d sink[16];
 	double sink64[16];
+	// in-kernel clock: shader cycles (s_memtime) over the 100 MHz constant counter (s_memrealtime), MI355X_MICROARCH.md DVFS item 6
+	const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
 	for (int it = 0; it < iters; it++) {
 #pragma unroll
 		for (int r = 0; r < R; r++) {
@@ -33,6 +35,8 @@ __global__ __launch_bounds__(128) void k_mix(double *out, int iters)
 		for (int f = 0; f < NF; f++) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[f % 16]) : "v"(0.999), "v"(0.001));
 		asm volatile("s_waitcnt lgkmcnt(0)");
 	}
+	const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+	if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = w1 - w0; }
 	double s = 0;
 	for (int i = 0; i < 16; i++) s += acc[i];
 	for (int r = 0; r < R; r++) {
@@ -59,14 +63,22 @@ template <typename F> static double time_ms(F f)
 
 template <int NF, int R, bool B64> static void run(double *out, int cus, int waves_per_simd)
 {
+	static unsigned long long *clk = nullptr;
+	if (!clk) (void)hipMallocManaged(&clk, sizeof(unsigned long long) * 2 * 256 * 8 * 2 * 2);
+
 	const int iters = 4000;
 	// 128-thread workgroups = 2 waves; waves_per_simd x 4 SIMDs x CUs waves in all, one round
 	dim3 grid(cus * waves_per_simd * 2), block(128);
-	const double ms = time_ms([&] { hipLaunchKernelGGL((k_mix<NF, R, B64>), grid, block, 0, 0, out, iters); });
+	const double ms = time_ms([&] { hipLaunchKernelGGL((k_mix<NF, R, B64>), grid, block, 0, 0, out, iters, clk); });
+	(void)hipDeviceSynchronize();
+	double mhz = 0;
+	const int nb = cus * waves_per_simd * 2;
+	for (int b = 0; b < nb; b++) mhz += (double)clk[2 * b] / (double)clk[2 * b + 1] * 100.0;
+	mhz /= nb;
 	// per SIMD: waves_per_simd waves x iters iterations; "cycles" at 2.4 GHz nominal, as in the other microbenchmarks
 	const double cyc = ms * 1e-3 * 2.4e9 / ((double)iters * waves_per_simd);
-	printf("  %2d fma + %2d %s, %d waves/SIMD: %7.3f ms  %6.1f cycles per wave-iteration per SIMD  (%.2f per fma)\n", NF, R,
-	       B64 ? "ds_read_b64 " : "ds_read_b128", waves_per_simd, ms, cyc, cyc / NF);
+	printf("  %2d fma + %2d %s, %d waves/SIMD: %7.3f ms  %6.1f cycles per wave-iteration per SIMD  (%.2f per fma); in-kernel clock %.0f MHz -> %.2f shader cycles per fma\n", NF, R,
+	       B64 ? "ds_read_b64 " : "ds_read_b128", waves_per_simd, ms, cyc, cyc / NF, mhz, NF ? cyc / NF * mhz / 2400.0 : 0.0);
 }
 
 int main()
