@@ -10,7 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <vector>
 
 #include "multiclust_hip.h"
@@ -33,6 +35,34 @@ struct mchip_comm {
 	unsigned long long n_reductions;	/* all-reduces completed on this communicator */
 	char err[512];
 };
+
+/* The RCCL that belongs to the HIP runtime this library is bound to.  A process can hold two ROCm stacks: PyTorch ships its own
+ * libamdhip64.so, librccl.so (no SONAME), librocm_smi64.so ... next to ROCm's.  When PyTorch is loaded first (bench.py), this
+ * library's "libamdhip64.so.7" resolves to PyTorch's runtime, and the RCCL to use is PyTorch's -- ROCm's librccl.so.1 beside it
+ * failed in ncclCommInitAll ("unhandled cuda error").  Without PyTorch (the command line) it is ROCm's.  So: the librccl in the
+ * directory of the libamdhip64 that hipGetDeviceCount resolves to; MCHIP_RCCL_PATH overrides; the loader's search path last. */
+static void *open_rccl(void)
+{
+	if (const char *path = getenv("MCHIP_RCCL_PATH")) {
+		void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+		if (h) return h;
+		fprintf(stderr, "mchip_comm_create: MCHIP_RCCL_PATH=%s: %s\n", path, dlerror());
+	}
+	Dl_info info;
+	if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+		std::string dir(info.dli_fname);
+		const size_t slash = dir.rfind('/');
+		if (slash != std::string::npos) {
+			dir.resize(slash + 1);
+			for (const char *n : { "librccl.so.1", "librccl.so" }) {
+				void *h = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL);
+				if (h) return h;
+			}
+		}
+	}
+	void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+	return h ? h : dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+}
 
 static int cfail(mchip_comm *c, int code, const char *what, const char *detail)
 {
@@ -57,8 +87,7 @@ int mchip_comm_create(mchip_comm **out, int n_devices, const int *devices)
 	c->devices.assign(devices, devices + n_devices);
 	c->cap = 0;
 	c->err[0] = 0;
-	c->dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-	if (!c->dl) c->dl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+	c->dl = open_rccl();
 	if (!c->dl) {
 		fprintf(stderr, "mchip_comm_create: cannot load RCCL: %s\n", dlerror());
 		delete c;

@@ -22,15 +22,18 @@ def owner_of(unit, world):
 
 def exchange(local_results, n_units, dist=None, device="cpu"):
     """local_results: iterable of McUnitResult (or objects with the same fields) for this rank's units.
-    Returns the list of all n_units results in unit order, identical on every rank (one all-reduce)."""
-    import torch
-    t = torch.zeros((n_units, len(FIELDS)), dtype=torch.float64, device=device)
+    Returns the list of all n_units results in unit order, identical on every rank (one all-reduce).
+    Without a process group (one rank, nothing to exchange) PyTorch is not touched: a process that loads it AFTER the HIP
+    library ends up with two HIP runtimes (PyTorch asks for "libamdhip64.so", ROCm's SONAME is "libamdhip64.so.7")."""
+    rows = [[0.0] * len(FIELDS) for _ in range(n_units)]
     for r in local_results:
-        t[r.unit] = torch.tensor([r.logL, r.converged, r.n_iter, r.time_stop, r.iter_stop, r.pindex, r.fatal, 1.0],
-                                 dtype=torch.float64)
+        rows[r.unit] = [float(r.logL), float(r.converged), float(r.n_iter), float(r.time_stop), float(r.iter_stop), float(r.pindex),
+                        float(r.fatal), 1.0]
     if dist is not None and dist.is_initialized():    # also with one rank: the rehearsal of the exchange on a one-GPU box
+        import torch
+        t = torch.tensor(rows, dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)      # rows are disjoint across ranks
-    rows = t.cpu().tolist()
+        rows = t.cpu().tolist()
     out = []
     for u, row in enumerate(rows):
         if row[7] != 1.0:

@@ -91,3 +91,43 @@ def test_two_communicators_in_one_process():
         t = np.arange(18.0)
         assert all_reduce(lib, comm, [t], 0) == 0 and np.array_equal(t, np.arange(18.0))
         assert lib.mchip_comm_destroy(comm) == 0
+
+
+COMM_SCRIPT = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+if %d:
+    import torch                                     # PyTorch's own librccl.so and HIP runtime are in the process first
+    torch.zeros(4, device="cuda").sum().item()
+import numpy as np
+from multiclust_amd import hip
+lib = hip.load()
+comm = C.c_void_p()
+rc = lib.mchip_comm_create(C.byref(comm), 1, (C.c_int * 1)(0))
+assert rc == 0, rc
+t = np.arange(27.0)
+bufs = (C.POINTER(C.c_double) * 1)(t.ctypes.data_as(C.POINTER(C.c_double)))
+assert lib.mchip_comm_all_reduce(comm, bufs, 27, 0) == 0 and np.array_equal(t, np.arange(27.0))
+ver = C.c_int()
+lib.mchip_comm_info(comm, None, C.byref(ver), None)
+rccl = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l]
+print("rccl", ver.value, sorted(set(rccl)))
+assert len(set(rccl)) == 1, rccl                     # one RCCL in the process, whoever brought it
+assert lib.mchip_comm_destroy(comm) == 0
+"""
+
+
+@pytest.mark.parametrize("torch_first", [0, 1])
+def test_one_rccl_per_process(torch_first):
+    """The communicator in a fresh process, without PyTorch (the command line's situation: ROCm's librccl.so.1 is loaded) and
+    with PyTorch imported and its GPU context up first (the Python bindings' situation: PyTorch's librccl.so is already there
+    and must be the one used -- a second RCCL beside it made ncclCommInitAll fail)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", COMM_SCRIPT % (root, torch_first)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.split("\n") if l.startswith("rccl ")][-1]
+    assert ("torch/lib/librccl.so" in line) == bool(torch_first), line
