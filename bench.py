@@ -224,6 +224,7 @@ def algorithmic_bytes(w, T, K=None):
         "column_pass": g + 16 * K * T + 8 * I * K,           # genotype + read P, write N-side sums + read Q
         "individual_pass": g + 8 * K * T + 16 * I * K,       # genotype + read P + read Q, write S-side sums
         "loglik_pass": g + 8 * K * T + 8 * I * K,
+        "individual_dual_pass": g + 16 * K * T + 24 * I * K,  # genotype + read P and Q of two parameter sets, write S-side sums
     }
 
 
@@ -328,7 +329,19 @@ def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0, units=1):
     fit.close()
     how = "on one core" if procs == 1 else "on each of %d processes at once (one unit each; rates summed: %.3f-%.3f it/s per process)" % (
         procs, min(rates), max(rates))
+    # the reference itself (stock build, one core of the planning container's 2.1 GHz Xeon) costs 34.7 ns per
+    # (individual, locus, cluster) cell on diploid biallelic data = 17 ns per (i, l, m, k) cell, the same at 500 x 5 000 and at
+    # 2 000 x 20 000.  It cannot run configs 3-5 (0.5 TB of diklm, O(n^2) reader): an extrapolation, labelled as one
+    ref_ns_per_cell = 17.0
+    ref_cells = float(I) * float(int(ua.sum())) * K
+    reference_extrapolated = {
+        "value": 1.0 / (ref_ns_per_cell * 1e-9 * ref_cells), "unit": "EM iterations/s", "cores": 1, "kind": "extrapolation",
+        "basis": "BASELINE.md section 2: %.0f ns per (i,l,m,k) cell measured for the unmodified reference on one 2.1 GHz Xeon core at "
+                 "config-1 and config-2 size, times I*T*K = %.3g cells; the reference cannot run this size (diklm alone is 0.5 TB at "
+                 "config 3), and its sources do not travel to the GPU box" % (ref_ns_per_cell, ref_cells),
+    }
     return {
+        "reference_extrapolated": reference_extrapolated,
         "value": sum(rates) * Ls / L, "unit": "EM iterations/s", "cores": procs, "kind": "port",
         "sample": "first %d of %d loci, all %d individuals, %d EM iterations (%s) in %.1f s %s; "
                   "scaled by %d/%d (cost is linear in loci)" % (Ls, L, I, mod.n_iter, "SQUAREM-3 cycles" if accel else "plain EM", dt, how, Ls, L),
@@ -337,11 +350,22 @@ def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0, units=1):
 
 
 # ------------------------------------------------------------------------------------------------ roofline object
+PASS_NAMES = ["column_pass", "individual_pass", "loglik_pass", "individual_dual_pass"]
+PASS_KERNELS = {"column_pass": ("k_column_counts", "k_column_counts (N-side sums)"),
+                "individual_pass": ("k_individual_sparse<2, true, false, true, false>", "k_individual_sparse (S-side sums + logL)"),
+                "loglik_pass": ("k_individual_sparse<2, false", "k_individual_sparse (stand-alone log likelihood)"),
+                "individual_dual_pass": ("k_individual_sparse<2, true, false, true, true>",
+                                         "k_individual_sparse, dual (S-side sums of the extrapolated point + logL of the second EM iterate)")}
+FP64_SUSTAINED_TF = 57.9     # v_fma_f64 stream with its in-kernel clock stamped: 1.79-1.92 GHz under FP64 load, 4.3-4.4 cycles per
+                             # wave-instruction (profiles/r03_lds_valu_microbench.txt); the spec peak assumes 2.4 GHz and 4.0
+
+
 def latest_traffic(tag):
-    """HBM bytes per launch from the PMC passes of this same command (scripts/summarize_profile.py; corrected as
-    MI355X_MICROARCH.md prescribes): the newest profiles/r*_<tag>_traffic.json, or None"""
+    """HBM bytes per launch from the PMC passes of this same command in an EARLIER run (scripts/summarize_profile.py; corrected
+    as MI355X_MICROARCH.md prescribes): (newest profiles/r*_<tag>_traffic.json, its name), or (None, None).  Counters cannot be
+    read inside a timed run; the line says where the figure comes from (`traffic_source`)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_traffic.json" % tag)))
-    return json.load(open(files[-1])) if files else None
+    return (json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)) if files else (None, None)
 
 
 def profile_begin(ctx):
@@ -349,43 +373,60 @@ def profile_begin(ctx):
     hip.load().mchip_profile_begin(ctx)
 
 
-def roofline_object(ctx, w, T, K, it_per_s_per_gpu, workload, nnz):
+def build_roofline(w, T, K, kernel_ms, launches, steps, it_per_s_per_gpu, nnz, traffic_table=None, traffic_file=None):
+    """The line's `roofline` object from the library's HIP-event figures: kernel_ms[x] / launches[x] = summed duration and number
+    of working launches of pass x (PASS_NAMES) over `steps` timed steps.  The dominant kernel is the pass with the most time per
+    step; `achieved` / `peak` / `frac` are its ALGORITHMIC bytes per launch over its average launch time against the HBM peak
+    (the contract's definition), `bound` says what actually binds it."""
+    B = algorithmic_bytes(w, T, K)
+    avg = [kernel_ms[x] / launches[x] if launches[x] else 0.0 for x in range(len(PASS_NAMES))]
+    per_step = [kernel_ms[x] / max(steps, 1) for x in range(len(PASS_NAMES))]
+    dom = max(range(len(PASS_NAMES)), key=lambda x: per_step[x])
+    name = PASS_NAMES[dom]
+    ach = B[name] / (avg[dom] * 1e-3) / 1e9 if avg[dom] else 0.0
+    flops_cell = 5 * K + 5                                   # SURVEY.md 8d: flops per non-empty cell (+ one log)
+    traffic = None
+    if traffic_table:
+        for kname, rec in traffic_table.items():
+            if kname.startswith(PASS_KERNELS[name][0]):
+                traffic = rec.get("hbm_bytes_per_launch_corrected")
+                break
+    return {
+        "bound": "fp64-valu", "kernel": PASS_KERNELS[name][1],
+        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        "traffic": traffic, "traffic_source": traffic_file if traffic is not None else None,
+        "algorithmic_bytes_per_launch": B[name], "avg_launch_ms": avg[dom],
+        "kernels_ms": {PASS_NAMES[x]: avg[x] for x in range(len(PASS_NAMES))},
+        "kernels_ms_per_step": {PASS_NAMES[x]: per_step[x] for x in range(len(PASS_NAMES))},
+        "launches": {PASS_NAMES[x]: launches[x] for x in range(len(PASS_NAMES))},
+        "pass_hbm_frac": {PASS_NAMES[x]: (B[PASS_NAMES[x]] / (avg[x] * 1e-3) / 1e9 / HBM_PEAK_GBS if avg[x] else 0.0)
+                          for x in range(len(PASS_NAMES))},
+        "iteration_bytes": B["iteration"],
+        "iteration_hbm_frac": B["iteration"] * it_per_s_per_gpu / 1e9 / HBM_PEAK_GBS,
+        "nonempty_cells": nnz, "dense_cells": w["I"] * T,
+        "fp64_valu_frac": flops_cell * nnz * it_per_s_per_gpu / 1e12 / FP64_VALU_PEAK_TF,
+        "fp64_valu_frac_dense_cells": flops_cell * w["I"] * T * it_per_s_per_gpu / 1e12 / FP64_VALU_PEAK_TF,
+        "fp64_valu_frac_of_sustained": flops_cell * w["I"] * T * it_per_s_per_gpu / 1e12 / FP64_SUSTAINED_TF,
+        "bound_note": "`bound` names what binds the kernel: FP64 vector issue.  `achieved`/`peak`/`frac` are the HBM figures the "
+                      "contract defines (algorithmic bytes per launch over the launch time against 8 TB/s); the HBM roof is not "
+                      "reachable at FP64 (about 45 flop per genotype byte at K = 8 against a ridge of 10).  fp64_valu_frac = "
+                      "(5K+5) flop per NON-EMPTY cell (SURVEY.md 8d; cells counted on the device at upload) x iterations/s over "
+                      "the 78.6 TF/s vector-FP64 spec peak; _dense_cells counts every (individual, allele column) cell, which is "
+                      "what the column pass multiplies through; _of_sustained is the same over the %.1f TF/s a pure v_fma_f64 "
+                      "stream sustains on this chip (the clock drops to 1.8-1.9 GHz under FP64 load: "
+                      "profiles/r03_lds_valu_microbench.txt)" % FP64_SUSTAINED_TF,
+    }
+
+
+def roofline_object(ctx, w, T, K, it_per_s_per_gpu, workload, nnz, steps):
     from multiclust_amd import hip
     hlib = hip.load()
     total_ms = C.c_double()
     km = (C.c_double * hip.PROF_KINDS)()
     kl = (C.c_int * hip.PROF_KINDS)()
     hlib.mchip_profile_end(ctx, C.byref(total_ms), km, kl)
-    B = algorithmic_bytes(w, T, K)
-    names = ["column_pass", "individual_pass", "loglik_pass", "individual_dual_pass"]
-    avg = [km[x] / kl[x] if kl[x] else 0.0 for x in range(hip.PROF_KINDS)]
-    dom = max(range(2), key=lambda x: avg[x])
-    ach = B[names[dom]] / (avg[dom] * 1e-3) / 1e9 if avg[dom] else 0.0
-    flops_cell = 5 * K + 5                                   # flops per non-empty cell (+ one log)
-    traffic = None
-    tj = latest_traffic("c3") if workload in ("c3", "c4") else None
-    if tj:
-        want = "k_column_counts" if dom == 0 else "k_individual_sparse<2, true"
-        for name, rec in tj.items():
-            if name.startswith(want):
-                traffic = rec.get("hbm_bytes_per_launch_corrected")
-                break
-    return {
-        "bound": "hbm", "kernel": "k_column_counts (N-side sums)" if dom == 0 else "k_individual_sparse (S-side sums + logL)",
-        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-        "algorithmic_bytes_per_launch": B[names[dom]], "avg_launch_ms": avg[dom],
-        "kernels_ms": {names[x]: avg[x] for x in range(hip.PROF_KINDS)},
-        "launches": {names[x]: kl[x] for x in range(hip.PROF_KINDS)},
-        "iteration_bytes": B["iteration"],
-        "iteration_hbm_frac": B["iteration"] * it_per_s_per_gpu / 1e9 / HBM_PEAK_GBS,
-        "nonempty_cells": nnz, "dense_cells": w["I"] * T,
-        "fp64_valu_frac": flops_cell * nnz * it_per_s_per_gpu / 1e12 / FP64_VALU_PEAK_TF,
-        "fp64_valu_frac_dense_cells": flops_cell * w["I"] * T * it_per_s_per_gpu / 1e12 / FP64_VALU_PEAK_TF,
-        "fp64_note": "kernels are FP64-issue-bound, not HBM-bound.  fp64_valu_frac = (5K+5) flop per NON-EMPTY cell (SURVEY.md 8d; "
-                     "cells counted on the device at upload) x iterations/s over the 78.6 TF/s vector-FP64 spec peak (best measured "
-                     "v_fma_f64 rate on this chip: %.1f TF/s); the _dense_cells figure counts every (individual, allele column) "
-                     "cell, which is what the column pass actually multiplies through" % FP64_VALU_MEASURED_TF,
-    }
+    table, fname = latest_traffic("c3") if workload in ("c3", "c4") else (None, None)
+    return build_roofline(w, T, K, list(km), list(kl), steps, it_per_s_per_gpu, nnz, table, fname)
 
 
 def data_counts(ctx):
@@ -469,9 +510,26 @@ def run_single_fit(args, env, name, ua, geno, steps, warmup, with_roofline=True)
     }
     if with_roofline and env.rank == 0:
         nnz, _ = data_counts(ctx)
-        out["roofline"] = roofline_object(ctx, w, T, w["K"], value / env.world, name, nnz)
+        out["roofline"] = roofline_object(ctx, w, T, w["K"], value / env.world, name, nnz, steps)
     elif with_roofline:
         hlib.mchip_profile_end(ctx, None, None, None)
+    if with_roofline and args.stability > 0:
+        # how stable is a figure taken over `steps` steps?  The same batch again, args.stability times, right behind the timed one,
+        # launched the same way (event pairs around the passes), each timed by itself on this rank: min / median / max
+        rates = []
+        profile_begin(ctx)
+        for _ in range(args.stability):
+            n0, t1 = fit.mod.n_iter, time.perf_counter()
+            run_steps(steps)
+            hlib.mchip_synchronize(ctx)
+            rates.append((fit.mod.n_iter - n0) / (time.perf_counter() - t1))
+        hlib.mchip_profile_end(ctx, None, None, None)
+        rates.sort()
+        out["stability"] = {"unit": "EM iterations/s on one GPU (rank 0)", "batches": len(rates), "steps_per_batch": steps,
+                            "min": rates[0], "median": rates[len(rates) // 2], "max": rates[-1],
+                            "timed_region": value / env.world,
+                            "note": "the timed region's batch repeated right behind it; clocks differ from box to box by +-6 % "
+                                    "(DESIGN.md 4.3), within a run by what this shows"}
     return out, fit, accel
 
 
@@ -520,7 +578,7 @@ def run_units(env, fit, w, T, n_units, cycles, warmup, with_roofline=True):
     }
     if with_roofline and env.rank == 0:
         nnz, _ = data_counts(ctx)
-        out["roofline"] = roofline_object(ctx, w, T, w["K"], total_iters / dt / env.world, "c4", nnz)
+        out["roofline"] = roofline_object(ctx, w, T, w["K"], total_iters / dt / env.world, "c4", nnz, len(mine) * cycles)
     elif with_roofline:
         hlib.mchip_profile_end(ctx, None, None, None)
     return out
@@ -639,7 +697,7 @@ def finish(env, args, out, scaling):
     # (nccl = RCCL), the collectives issued on it and the data-set checksum every rank agreed on before the timed region
     line["exchange"] = {"backend": env.backend if env.dist is not None else "none", "collectives": env.collectives,
                         "data_crc32_all_ranks": WORKLOADS[args.workload].get("data_crc32")}
-    for k in ("roofline", "cpu_baseline", "secondary"):
+    for k in ("roofline", "cpu_baseline", "stability", "secondary"):
         if k in out:
             line[k] = out[k]
     emit(json.dumps(line))
@@ -660,6 +718,8 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="c5: concurrent replicates per GPU (host thread + contexts + streams each)")
     ap.add_argument("--settle", type=float, default=1.5, help="seconds of untimed log-likelihood passes before the warm-up steps of a "
                     "single-fit workload, so that the timed steps run at the clocks of a busy device (0: none)")
+    ap.add_argument("--stability", type=int, default=5, help="single-fit workloads: repeat the timed batch this many times behind the "
+                    "timed region and report min / median / max EM iterations/s (0: off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra workloads carried on the default line (profiling "

@@ -209,6 +209,12 @@ int mchip_get_expected_counts(mchip_context *ctx, double *sik);
 /* ---- acceleration (accel_em.c, em_alg.c:1072-1211) ---- */
 /* u (which=0) or v (which=1) secant j := x[to] - x[from], for p and eta (em_alg.c:1104-1161). */
 int mchip_secant(mchip_context *ctx, int which, int j, int to, int from);
+/* The secant buffers as model state: mod->u_pklm[j] / v_pklm[j] (which = 0 / 1) with u_etaik[j] / v_etaik[j] (or u_etak / v_etak),
+ * multiclust.h:284-293, allocated by allocate_model_for_k (multiclust.c:1231-1258); p_part in the flat order of a P slot
+ * (double[K*T]), q_part in that of a Q slot.  Together with the parameter slots and model::delta_index they are the whole state
+ * of a quasi-Newton run with q > 1 between two cycles (em_alg.c:1171 rotates the slot the next pair goes to). */
+int mchip_set_secant(mchip_context *ctx, int which, int j, const double *p_part, const double *q_part);
+int mchip_get_secant(mchip_context *ctx, int which, int j, double *p_part, double *q_part);
 /* utu, utvu, vutvu of secant pair j, eta terms then p terms (accel_em.c:143-184). out[3]. */
 int mchip_step_dots(mchip_context *ctx, int j, double *out3);
 /* u_{j1}.u_{j2} and u_{j1}.v_{j2} (quasi-Newton secant matrix, accel_em.c:291-310). out[2]. */

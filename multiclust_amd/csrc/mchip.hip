@@ -825,11 +825,10 @@ __device__ __forceinline__ double ordered_sum(double acc, const double *__restri
 	return acc;
 }
 
-/* deterministic sum of n doubles (fixed strided order, then a fixed tree): one block */
-__global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_sum(const double *__restrict__ in, int n, double *out, const int *stop = nullptr)
+/* deterministic sum of n doubles by one block (fixed strided order, then a fixed tree); every thread must call it; the result is
+ * valid in thread 0 (and red[] may be reused after the trailing barrier) */
+__device__ __forceinline__ double block_ordered_sum(const double *__restrict__ in, int n, double *red)
 {
-	__shared__ double red[MCHIP_BLOCK];
-	if (stop && *stop) return;
 	const double s = (int)threadIdx.x < n ? ordered_sum(0.0, in, threadIdx.x, MCHIP_BLOCK, (n - (int)threadIdx.x + MCHIP_BLOCK - 1) / MCHIP_BLOCK) : 0.0;
 	red[threadIdx.x] = s;
 	__syncthreads();
@@ -837,7 +836,33 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_sum(const double *__rest
 		if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) *out = red[0];
+	const double v = red[0];
+	__syncthreads();
+	return v;
+}
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_sum(const double *__restrict__ in, int n, double *out, const int *stop = nullptr)
+{
+	__shared__ double red[MCHIP_BLOCK];
+	if (stop && *stop) return;
+	const double v = block_ordered_sum(in, n, red);
+	if (threadIdx.x == 0) *out = v;
+}
+/* the end of a batched accelerated cycle in one single-block launch: emll (when in1 is given: the dual pass's second log
+ * likelihood) -> sc[1], the extrapolated point's log likelihood -> sc[2] (k_reduce_sum's sums), accept iff ll > emll */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_accept(const double *__restrict__ in1, const double *__restrict__ in2, int n, double *sc,
+		int *cyc, const int *stop)
+{
+	__shared__ double red[MCHIP_BLOCK];
+	if (stop && *stop) return;
+	if (in1) {
+		const double v = block_ordered_sum(in1, n, red);
+		if (threadIdx.x == 0) sc[1] = v;
+	}
+	const double v2 = block_ordered_sum(in2, n, red);
+	if (threadIdx.x == 0) {
+		sc[2] = v2;
+		cyc[1] = (!cyc[0] && sc[2] > sc[1]) ? 1 : 0;
+	}
 }
 
 /* the 2 * nout sums of a dot-product pass in one launch (block x < nout: eta part x -> sc[16 + x]; the others: p part -> sc[20 + .]):
@@ -851,14 +876,8 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_dots(const double *__res
 	const double *in = x < nout ? part_q + (size_t)x * gq : part_p + (size_t)(x - nout) * gp;
 	const int n = x < nout ? gq : gp;
 	double *out = x < nout ? sc + 16 + x : sc + 20 + (x - nout);
-	const double s = (int)threadIdx.x < n ? ordered_sum(0.0, in, threadIdx.x, MCHIP_BLOCK, (n - (int)threadIdx.x + MCHIP_BLOCK - 1) / MCHIP_BLOCK) : 0.0;
-	red[threadIdx.x] = s;
-	__syncthreads();
-	for (int w = MCHIP_BLOCK / 2; w > 0; w >>= 1) {
-		if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-		__syncthreads();
-	}
-	if (threadIdx.x == 0) *out = red[0];
+	const double v = block_ordered_sum(in, n, red);
+	if (threadIdx.x == 0) *out = v;
 }
 
 /* out[e] = sum over slabs of slabs[j][e], in a fixed order: a block handles 32 elements x 8 slab lanes (lane s adds
@@ -1138,13 +1157,13 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_dots(const double *__restrict__
 /* k_dots (mode 0) and k_accel_update of a batched cycle straight from the three iterates: u = x1 - x0 and v = x2 - x1 are formed
  * where they are used -- the values k_diff would have stored, so the sums and the update keep their bits -- and the cycle has
  * four launches and 100 MB of traffic less */
-__global__ __launch_bounds__(MCHIP_BLOCK) void k_dots_slots(const double *__restrict__ x0, const double *__restrict__ x1,
-		const double *__restrict__ x2, size_t n, double *part, const int *stop)
+/* block `bid` of `gdim` of the dot-product pass over one array (u = x1 - x0, v = x2 - x1 formed here): grid-stride partial sums, a
+ * fixed tree per block, three partials per block */
+__device__ __forceinline__ void dots_slots_body(const double *__restrict__ x0, const double *__restrict__ x1, const double *__restrict__ x2,
+		size_t n, double *part, unsigned bid, unsigned gdim, double (*red)[MCHIP_BLOCK])
 {
-	__shared__ double red[3][MCHIP_BLOCK];
-	if (stop && *stop) return;
 	double s0 = 0, s1 = 0, s2 = 0;
-	for (size_t x = (size_t)blockIdx.x * MCHIP_BLOCK + threadIdx.x; x < n; x += (size_t)gridDim.x * MCHIP_BLOCK) {
+	for (size_t x = (size_t)bid * MCHIP_BLOCK + threadIdx.x; x < n; x += (size_t)gdim * MCHIP_BLOCK) {
 		const double uu = x1[x] - x0[x], vv = x2[x] - x1[x];
 		const double d = vv - uu;
 		s0 += uu * uu; s1 += uu * d; s2 += d * d;
@@ -1160,17 +1179,33 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_dots_slots(const double *__rest
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) {
-		part[blockIdx.x] = red[0][0];
-		part[gridDim.x + blockIdx.x] = red[1][0];
-		part[2 * gridDim.x + blockIdx.x] = red[2][0];
+		part[bid] = red[0][0];
+		part[gdim + bid] = red[1][0];
+		part[2 * gdim + bid] = red[2][0];
 	}
 }
-__global__ void k_accel_update_slots(const double *__restrict__ x0, const double *x1, const double *__restrict__ x2, double *out, size_t n,
+/* the eta part (blocks 0 .. gq-1) and the p part (the other gp blocks) of the step-size dot products in one launch; every block
+ * does what it did when the two parts were two launches */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_dots_slots(const double *__restrict__ q0, const double *__restrict__ q1,
+		const double *__restrict__ q2, size_t nq, double *part_q, unsigned gq, const double *__restrict__ p0,
+		const double *__restrict__ p1, const double *__restrict__ p2, size_t np, double *part_p, const int *stop)
+{
+	__shared__ double red[3][MCHIP_BLOCK];
+	if (stop && *stop) return;
+	if (blockIdx.x < gq) dots_slots_body(q0, q1, q2, nq, part_q, blockIdx.x, gq, red);
+	else dots_slots_body(p0, p1, p2, np, part_p, blockIdx.x - gq, gridDim.x - gq, red);
+}
+/* x_B = x_A - 2 s u + s^2 (v - u) (or x_A + u + s v) for the eta array (threads below nq) and the p array in one launch */
+__global__ void k_accel_update_slots(const double *__restrict__ q0, const double *q1, const double *__restrict__ q2, double *qout, size_t nq,
+				     const double *__restrict__ p0, const double *p1, const double *__restrict__ p2, double *pout, size_t np,
 				     int qn_form, const double *s_dev, const int *stop)
 {
 #pragma clang fp contract(off)
-	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= n || (stop && *stop)) return;
+	size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= nq + np || (stop && *stop)) return;
+	const double *x0 = q0, *x1 = q1, *x2 = q2;
+	double *out = qout;
+	if (idx >= nq) { idx -= nq; x0 = p0; x1 = p1; x2 = p2; out = pout; }
 	const double s = *s_dev;
 	const double u = x1[idx] - x0[idx], v = x2[idx] - x1[idx];	/* (out may be x1: read before written, element by element) */
 	if (qn_form) out[idx] = x0[idx] + u + s * v;
@@ -1205,9 +1240,8 @@ __global__ void k_add(const double *__restrict__ a, const double *__restrict__ b
 /* step_size() of accel_em.c:130-243 on the device (batched accelerated runs): sc[16..18] / sc[20..22] are the eta / p
  * parts of utu, u(v-u), (v-u)^2 (eta terms first, accel_em.c:143-184); the step goes to sc[24]; cyc[0] = 1 when the
  * reference would leave the cycle without an update (NaN / infinite step, S3's sqrt(utu) < 1e-8 guard) */
-__global__ void k_step_size(double *sc, int scheme, int *cyc, const int *stop)
+__device__ __forceinline__ void step_size_body(double *sc, int scheme, int *cyc)
 {
-	if (threadIdx.x || blockIdx.x || (stop && *stop)) return;
 	const double utu = sc[16] + sc[20], utvu = sc[17] + sc[21], vutvu = sc[18] + sc[22];
 	double s;
 	if (scheme == 1) s = utu / utvu;
@@ -1218,9 +1252,21 @@ __global__ void k_step_size(double *sc, int scheme, int *cyc, const int *stop)
 	sc[24] = s;
 	cyc[0] = (s != s || s - s != 0.0) ? 1 : 0;	/* isnan || isinf */
 }
-
-/* accept iff ll(extrapolated) > ll(second EM iterate) (accel_em.c:88); cyc[1] = accepted, which is also "the S-side sums of
- * the next cycle's first E step are already in place" */
+/* the six sums of the step-size dot products (k_reduce_dots's blocks, one after the other: same order, same tree, same bits) and
+ * step_size (accel_em.c:130-243) in one single-block launch */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_reduce_dots_step(const double *__restrict__ part_q, int gq, const double *__restrict__ part_p,
+		int gp, double *sc, int scheme, int *cyc, const int *stop)
+{
+	__shared__ double red[MCHIP_BLOCK];
+	if (stop && *stop) return;
+	for (int x = 0; x < 6; x++) {
+		const double *in = x < 3 ? part_q + (size_t)x * gq : part_p + (size_t)(x - 3) * gp;
+		const int n = x < 3 ? gq : gp;
+		const double v = block_ordered_sum(in, n, red);
+		if (threadIdx.x == 0) sc[(x < 3 ? 16 : 20) + (x % 3)] = v;
+	}
+	if (threadIdx.x == 0) step_size_body(sc, scheme, cyc);
+}
 __global__ void k_accept(const double *sc, int *cyc, const int *stop)
 {
 	if (threadIdx.x || blockIdx.x || (stop && *stop)) return;
@@ -1229,12 +1275,14 @@ __global__ void k_accept(const double *sc, int *cyc, const int *stop)
 
 /* the cycle's outcome goes back to the slot every cycle starts from: the extrapolated point if accepted, else the second
  * EM iterate (pindex = tindex / findex, accel_em.c:89-101), so that the slot roles are the same in every cycle */
-__global__ void k_select_copy(double *dst, const double *__restrict__ if_accepted, const double *__restrict__ otherwise, size_t n,
+__global__ void k_select_copy(double *qdst, const double *__restrict__ q_if_accepted, const double *__restrict__ q_otherwise, size_t nq,
+			      double *pdst, const double *__restrict__ p_if_accepted, const double *__restrict__ p_otherwise, size_t np,
 			      const int *cyc, const int *stop)
 {
-	const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= n || (stop && *stop)) return;
-	dst[idx] = cyc[1] ? if_accepted[idx] : otherwise[idx];
+	size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= nq + np || (stop && *stop)) return;
+	if (idx < nq) qdst[idx] = cyc[1] ? q_if_accepted[idx] : q_otherwise[idx];
+	else { idx -= nq; pdst[idx] = cyc[1] ? p_if_accepted[idx] : p_otherwise[idx]; }
 }
 
 /* ------------------------------------------------------------------ helpers */
@@ -2493,6 +2541,37 @@ static int check_secant(mchip_context *ctx, int j)
 	return MCHIP_OK;
 }
 
+/* the secant buffers as model state (mod->u_pklm / v_pklm / u_etaik / v_etaik, multiclust.h:284-293): written and read whole, in
+ * the parameter slots' own flat order, so that a quasi-Newton run with q > 1 can be resumed from a recorded state */
+int mchip_set_secant(mchip_context *ctx, int which, int j, const double *p_part, const double *q_part)
+{
+	int rc = check_secant(ctx, j);
+	if (rc) return rc;
+	if (!p_part || !q_part || (which != 0 && which != 1)) return fail(ctx, MCHIP_ERR_INVALID, "set_secant: bad arguments%s", nullptr);
+	const size_t KT = (size_t)ctx->K * ctx->T;
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipMemcpyAsync(ctx->d_stage, p_part, KT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(k_transpose_kt_to_tk, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_stage, which ? ctx->d_vp[j] : ctx->d_up[j], ctx->K, ctx->T);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(which ? ctx->d_vq[j] : ctx->d_uq[j], q_part, (size_t)ctx->nq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+int mchip_get_secant(mchip_context *ctx, int which, int j, double *p_part, double *q_part)
+{
+	int rc = check_secant(ctx, j);
+	if (rc) return rc;
+	if (!p_part || !q_part || (which != 0 && which != 1)) return fail(ctx, MCHIP_ERR_INVALID, "get_secant: bad arguments%s", nullptr);
+	const size_t KT = (size_t)ctx->K * ctx->T;
+	HIPCHK(hipSetDevice(ctx->device));
+	hipLaunchKernelGGL(k_transpose_tk_to_kt, dim3(nblk(KT)), dim3(256), 0, ctx->stream, which ? ctx->d_vp[j] : ctx->d_up[j], ctx->d_stage, ctx->K, ctx->T);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(p_part, ctx->d_stage, KT * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipMemcpyAsync(q_part, which ? ctx->d_vq[j] : ctx->d_uq[j], (size_t)ctx->nq * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return MCHIP_OK;
+}
+
 int mchip_secant(mchip_context *ctx, int which, int j, int to, int from)
 {
 	int rc = check_secant(ctx, j);
@@ -2616,15 +2695,15 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 		const int gq = (int)((ctx->nq + 4095) / 4096) > 512 ? 512 : (int)((ctx->nq + 4095) / 4096);
 		const int gp = (int)((KT + 4095) / 4096) > 512 ? 512 : (int)((KT + 4095) / 4096);
 		double *part_q = ctx->d_redpart, *part_p = ctx->d_redpart + 3 * 512;
-		hipLaunchKernelGGL(k_dots_slots, dim3(gq), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_q[A], ctx->d_q[B], ctx->d_q[C], nq, part_q, stop);
-		hipLaunchKernelGGL(k_dots_slots, dim3(gp), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_p[A], ctx->d_p[B], ctx->d_p[C], KT, part_p, stop);
-		hipLaunchKernelGGL(k_reduce_dots, dim3(6), dim3(MCHIP_BLOCK), 0, ctx->stream, part_q, gq, part_p, gp, 3, ctx->d_scalars, stop);
+		hipLaunchKernelGGL(k_dots_slots, dim3(gq + gp), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_q[A], ctx->d_q[B], ctx->d_q[C], nq, part_q, (unsigned)gq,
+				   ctx->d_p[A], ctx->d_p[B], ctx->d_p[C], KT, part_p, stop);
+		/* step size (accel_em.c:130-243) -> d_scalars[24], by the launch that adds up the partial dot products */
+		hipLaunchKernelGGL(k_reduce_dots_step, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, part_q, gq, part_p, gp, ctx->d_scalars, scheme, cyc, stop);
 	}
-	hipLaunchKernelGGL(k_step_size, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars, scheme, cyc, stop);
 	/* accelerated_update (accel_em.c:422-551): B = A - 2 s u + s^2 (v - u) (or A + u + s v), projected; its log likelihood,
 	 * taken by the pass that also leaves the S-side sums -> d_scalars[2] */
-	hipLaunchKernelGGL(k_accel_update_slots, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[A], ctx->d_p[B], ctx->d_p[C], ctx->d_p[B], KT, scheme == 4, ctx->d_scalars + 24, stop);
-	hipLaunchKernelGGL(k_accel_update_slots, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[A], ctx->d_q[B], ctx->d_q[C], ctx->d_q[B], nq, scheme == 4, ctx->d_scalars + 24, stop);
+	hipLaunchKernelGGL(k_accel_update_slots, dim3(nblk(nq + KT)), dim3(256), 0, ctx->stream, ctx->d_q[A], ctx->d_q[B], ctx->d_q[C], ctx->d_q[B], nq,
+			   ctx->d_p[A], ctx->d_p[B], ctx->d_p[C], ctx->d_p[B], KT, scheme == 4, ctx->d_scalars + 24, stop);
 	if ((rc = project_slot(ctx, B, stop))) return rc;
 	if (!ctx->admixture) {
 		if ((rc = run_mixture(ctx, B, B, 0, 1, stop, 2))) return rc;	/* nothing of this pass serves the next E step */
@@ -2633,7 +2712,6 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 			prof_mark(ctx, MCHIP_KERN_DUAL, true);
 			ctx->kt->accum_q_dual(dual, ctx->stream);
 			prof_mark(ctx, MCHIP_KERN_DUAL, false);
-			hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart2, ctx->n_ll_ind, ctx->d_scalars + 1, stop);
 		} else {
 			mchip_pass_args a = pass_args(ctx, B);
 			a.stop = stop;
@@ -2641,12 +2719,15 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 			ctx->kt->accum_q(a, ctx->stream);
 			prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
 		}
-		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_ll_ind, ctx->d_scalars + 2, stop);
 	}
-	/* accept iff ll > emll; the outcome goes back to slot A */
-	hipLaunchKernelGGL(k_accept, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars, cyc, stop);
-	hipLaunchKernelGGL(k_select_copy, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[A], ctx->d_p[B], ctx->d_p[C], KT, cyc, stop);
-	hipLaunchKernelGGL(k_select_copy, dim3(nblk(nq)), dim3(256), 0, ctx->stream, ctx->d_q[A], ctx->d_q[B], ctx->d_q[C], nq, cyc, stop);
+	/* the two log likelihoods' sums and accept iff ll > emll, one launch; the outcome goes back to slot A */
+	if (ctx->admixture)
+		hipLaunchKernelGGL(k_reduce_accept, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, use_dual ? ctx->d_llpart2 : (const double *)nullptr, ctx->d_llpart,
+				   ctx->n_ll_ind, ctx->d_scalars, cyc, stop);
+	else
+		hipLaunchKernelGGL(k_accept, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars, cyc, stop);
+	hipLaunchKernelGGL(k_select_copy, dim3(nblk(nq + KT)), dim3(256), 0, ctx->stream, ctx->d_q[A], ctx->d_q[B], ctx->d_q[C], nq,
+			   ctx->d_p[A], ctx->d_p[B], ctx->d_p[C], KT, cyc, stop);
 	HIPCHK(hipGetLastError());
 	return MCHIP_OK;
 }

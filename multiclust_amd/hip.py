@@ -73,6 +73,8 @@ def load():
         "mchip_init_from_allele_centers": ([vp, vp, vp, vp, C.c_uint64, i32], i32),
         "mchip_copy_slot": ([vp, i32, i32], i32),
         "mchip_secant": ([vp, i32, i32, i32, i32], i32),
+        "mchip_set_secant": ([vp, i32, i32, vp, vp], i32),
+        "mchip_get_secant": ([vp, i32, i32, vp, vp], i32),
         "mchip_step_dots": ([vp, i32, dp], i32),
         "mchip_secant_dots": ([vp, i32, i32, dp], i32),
         "mchip_accel_update": ([vp, i32, i32, i32, C.c_double, i32], i32),
@@ -87,6 +89,8 @@ def load():
         "mchip_comm_info": ([vp, ip, ip, C.POINTER(C.c_ulonglong)], i32),
     }
     for name, (args, res) in sig.items():
+        if "MCHIP_LIB_PATH" in os.environ and not hasattr(lib, name):
+            continue                   # an older experimental build under comparison (scripts/diag/bits.sh); the product library
         fn = getattr(lib, name)        # AttributeError here = the library does not export its own header
         fn.argtypes = args
         fn.restype = res
@@ -100,7 +104,7 @@ ABI_SYMBOLS = [
     "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_em_run", "mchip_accel_run", "mchip_last_loglik", "mchip_e_step",
     "mchip_loglik", "mchip_loglik_prefetch", "mchip_mstep_from_partition", "mchip_mstep_from_rand_partition",
     "mchip_get_genotypes", "mchip_data_counts", "mchip_copy_genotypes", "mchip_simulate_genotypes", "mchip_set_init_genotypes",
-    "mchip_get_expected_counts", "mchip_init_from_allele_centers", "mchip_copy_slot", "mchip_secant", "mchip_step_dots",
+    "mchip_get_expected_counts", "mchip_init_from_allele_centers", "mchip_copy_slot", "mchip_secant", "mchip_set_secant", "mchip_get_secant", "mchip_step_dots",
     "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
     "mchip_profile_end", "mchip_device_info", "mchip_comm_create", "mchip_comm_all_reduce", "mchip_comm_destroy",
     "mchip_comm_last_error", "mchip_comm_info",

@@ -70,18 +70,54 @@ BOOTSTRAP_EM_CASES = ("multi_admix_k4_noproj", "rare_admix_k3_noproj", "rare_adm
 # section 3b also records the iterate every accelerated cycle starts from (stride 1 = every cycle; n: cycles c, c+1 of every n)
 CYCLE_STATE_CASES = {"c1_admix_k3": 6, "multi_admix_k4": 1, "multi_admix_k4_s1": 1, "multi_admix_k4_s2": 1,
                      "multi_admix_k3_qn1": 1, "tetra_admix_k3": 1, "missing_admix_k3": 1, "multi_admix_c_k3": 1,
-                     "multi_admix_k4_tinybound": 2, "mixslow_mix_k3_s3": 1, "mixslow_mix_k3_qn1": 1}
+                     "multi_admix_k4_tinybound": 2, "mixslow_mix_k3_s3": 1, "mixslow_mix_k3_qn1": 1,
+                     # quasi-Newton with two and three secant pairs (the pairs and delta_index travel with every state), and SQUAREM
+                     # with step back-tracking (-g)
+                     "multi_admix_k3_qn2": 1, "multi_admix_k3_qn3": 1, "mixslow_mix_k3_qn2": 1, "mixslow_mix_k3_qn3": 1,
+                     "multi_admix_k4_g3": 1, "multi_admix_k4_s1_g2": 1}
 RANDEM_CASES = {"multi_admix_k3_randem": 6, "wide_admix_k2_randem": 5, "tetra_admix_k3_randem": 4,
                 "missing_admix_k2_randem": 5, "multi_admix_c_k3_randem": 4, "multi_mix_k3_randem": 5}
+
+
+# Every reference process runs in a fresh directory /tmp/mcfix.XXXXXXXX (fixed name length) on a copy of its input files, with a
+# fixed minimal environment: what the reference reads from uninitialised heap memory (the phantom allele slot of a locus with
+# missing data, read_file.c:527-533 vs 581-585) then does not depend on where this checkout lies or on
+# the caller's environment, and `python oracle/make_fixtures.py` gives the same bytes from any checkout path.
+FIXED_ENV = {"PATH": "/usr/bin:/bin", "LC_ALL": "C"}
+CLI_RECORD = {}
+
+
+def scratch_copy(files, attempt=1):
+    """attempt n lengthens the directory name by n - 1 characters: the reference's heap layout (and with it what the
+    uninitialised phantom slots hold, and whether its free() aborts) depends on the lengths of the path strings it copies"""
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="mcfix." + "x" * (attempt - 1), dir="/tmp")
+    local = []
+    for f in files:
+        dst = os.path.join(tmp, os.path.basename(f))
+        shutil.copyfile(f, dst)
+        local.append(dst)
+    return tmp, local
+
+
+def phantom_slots(stru, ploidy):
+    """{locus: index of the phantom allele slot} for loci with missing data in a non-interleaved STRUCTURE file whose missing
+    code is -9: the reference counts a slot for MISSING but lists only the real alleles (ascending), so the last slot is
+    uninitialised memory"""
+    rows = [l.split()[2:] for l in open(stru).read().strip().split("\n")[1:]]
+    out = {}
+    for l in range(len(rows[0])):
+        codes = set(r[l] for r in rows)
+        if "-9" in codes:
+            out[l] = len(codes) - 1
+    return out
 
 
 def run(name, stru, n_em, snaps, n_cycles, args, keep_ilm=True):
     out = os.path.join(GOLD, name)
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)
-    cmd = [HARNESS, out, str(n_em), snaps, str(n_cycles), "--", "-f", stru] + args
-    print(" ".join(cmd))
-    env = dict(os.environ)
+    env = dict(FIXED_ENV)
     if name in BOOTSTRAP_CASES:     # section 6 of the harness: one parametric-bootstrap data set (bs_ilm.u8)
         env["REF_HARNESS_BOOTSTRAP"] = "1"
     if name in BOOTSTRAP_EM_CASES:
@@ -90,7 +126,25 @@ def run(name, stru, n_em, snaps, n_cycles, args, keep_ilm=True):
         env["REF_HARNESS_CYCLE_STATES"] = str(CYCLE_STATE_CASES[name])
     if name in RANDEM_CASES:
         env["REF_HARNESS_RANDEM"] = str(RANDEM_CASES[name])
-    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, cwd=out, env=env)
+    for attempt in range(1, 9):
+        # the harness itself refuses a run in which heap garbage matched an allele code ("phantom allele slot has counts"):
+        # try again from a scratch directory with a longer name (another heap layout)
+        tmp, (local,) = scratch_copy([stru], attempt)
+        work = os.path.join(tmp, "o")
+        os.makedirs(work)
+        cmd = [HARNESS, work, str(n_em), snaps, str(n_cycles), "--", "-f", local] + args
+        print(" ".join(cmd))
+        res = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, cwd=work, env=env, text=True)
+        if res.returncode == 0:
+            break
+        shutil.rmtree(tmp)
+        if "phantom allele slot has counts" not in res.stderr:
+            sys.exit("%s: the harness failed: %s" % (name, res.stderr[-2000:]))
+    else:
+        sys.exit("%s: heap garbage matched an allele code in every attempt" % name)
+    for fn in os.listdir(work):
+        shutil.copyfile(os.path.join(work, fn), os.path.join(out, fn))
+    shutil.rmtree(tmp)
     with open(os.path.join(out, "manifest.json")) as f:
         json.load(f)                # the reference exit(0)s on NaN / decrease: a truncated manifest is a failed fixture
     with open(os.path.join(out, "ARGS.txt"), "w") as f:
@@ -105,18 +159,51 @@ def run(name, stru, n_em, snaps, n_cycles, args, keep_ilm=True):
 REFBIN = os.path.join(ROOT, "oracle", "_ref", "multiclust_ref")
 
 
-def run_cli(name, stru, args):
-    """The reference's own command line on a fixture: stdout and the five output files, kept as golden data."""
+def run_cli(name, stru, args, ploidy=2):
+    """The reference's own command line on a fixture: stdout and the five output files, kept as golden data.  With missing data
+    the run is only kept when every phantom allele slot came out at its floor (printed 0.000000 in *.pklm.txt) and the process
+    ended normally: a run in which heap garbage happened to equal an allele code fits a different model (and usually aborts in
+    free()).  What was checked is recorded in tests/golden/CLI_MANIFEST.json."""
     out = os.path.join(GOLD, "cli_" + name)
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)
-    cmd = [REFBIN, "-f", stru, "-d", out] + args
-    print(" ".join(cmd))
-    res = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=out, text=True)
-    with open(os.path.join(out, "stdout.txt"), "w") as f:
-        f.write(res.stdout.replace(stru, os.path.basename(stru)))
+    side = [a for a in args if os.path.isabs(a)]            # -P / -Q files
+    phantom = phantom_slots(stru, ploidy)
+    env = dict(FIXED_ENV)
+    for attempt in range(1, 9):
+        tmp, local = scratch_copy([stru] + side, attempt)
+        work = os.path.join(tmp, "o")
+        os.makedirs(work)
+        largs = [local[1 + side.index(a)] if a in side else a for a in args]
+        cmd = [REFBIN, "-f", local[0], "-d", work] + largs
+        print(" ".join(cmd))
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=work, env=env, text=True)
+        bad = None
+        if res.returncode != 0:
+            bad = "exit status %d" % res.returncode
+        else:
+            for fn in os.listdir(work):
+                if fn.endswith("pklm.txt"):
+                    for row in open(os.path.join(work, fn)).read().strip().split("\n")[1:]:
+                        k, l, m, v = row.split()
+                        if phantom.get(int(l)) == int(m) and v != "0.000000":
+                            bad = "phantom slot of locus %s holds %s" % (l, v)
+        if bad is None:
+            break
+        print("   attempt %d rejected: %s" % (attempt, bad))
+        shutil.rmtree(tmp)
+    else:
+        sys.exit("cli_%s: no clean run in 8 attempts" % name)
+    for fn in os.listdir(work):
+        shutil.copyfile(os.path.join(work, fn), os.path.join(out, fn))
+    with open(os.path.join(out, "stdout.txt"), "w") as f:      # elapsed CPU time is not data: masked, so that a re-run gives the same bytes
+        import re
+        f.write(re.sub(r"\d\d:\d\d:\d\d", "HH:MM:SS", res.stdout.replace(local[0], os.path.basename(stru))))
+    shutil.rmtree(tmp)
     with open(os.path.join(out, "ARGS.txt"), "w") as f:      # files are named by their base names (they live in tests/golden/data)
         f.write(" ".join(["-f", os.path.basename(stru)] + [os.path.basename(a) if os.path.isabs(a) else a for a in args]) + "\n")
+    CLI_RECORD["cli_" + name] = {"loci_with_a_phantom_allele_slot": len(phantom), "attempts": attempt,
+                                 "kept": "exit status 0; every phantom slot printed 0.000000 (no heap garbage matched an allele code)"}
 
 
 def write_interleaved(src, dst, ploidy):
@@ -160,6 +247,10 @@ def main():
     run("multi_admix_k3_qn1", multi, 3, "1,3", 3, ["-a", "-k", "3", "-r", "7", "-s", "4"])
     run("multi_admix_k3_qn2", multi, 3, "1,3", 3, ["-a", "-k", "3", "-r", "7", "-s", "5"])
     run("multi_admix_k3_qn3", multi, 3, "1,3", 3, ["-a", "-k", "3", "-r", "7", "-s", "6"])
+    # step back-tracking (-g n, accel_em.c:67-82): when the extrapolated point is worse than the EM iterate the step is halved
+    # towards -1, up to n times
+    run("multi_admix_k4_g3", multi, 3, "1,3", 3, ["-a", "-k", "4", "-r", "7", "-s", "3", "-g", "3"])
+    run("multi_admix_k4_s1_g2", multi, 3, "1,3", 3, ["-a", "-k", "4", "-r", "7", "-s", "1", "-g", "2"])
     run("multi_admix_k1", multi, 2, "1,2", 0, ["-a", "-k", "1", "-r", "7"])
     run("tetra_admix_k3", tetra, 20, "1,2,3,20", 3, ["-p", "4", "-a", "-k", "3", "-r", "11", "-s", "3"])
     run("missing_admix_k3", miss, 20, "1,2,3,20", 3, ["-a", "-k", "3", "-r", "5", "-s", "3"])
@@ -229,7 +320,7 @@ def main():
     run_cli("multi_mix_k3", multi, ["-k", "3", "-r", "5", "-n", "2"])
     run_cli("multi_admix_c_k3", multi, ["-a", "-c", "-k", "3", "-r", "5", "-n", "2"])
     # (a K range, -1 <a> -2 <b>, aborts inside the reference itself after the first K: "free(): invalid pointer")
-    run_cli("tetra_admix_k3", tetra, ["-p", "4", "-a", "-k", "3", "-r", "11", "-n", "2"])
+    run_cli("tetra_admix_k3", tetra, ["-p", "4", "-a", "-k", "3", "-r", "11", "-n", "2"], ploidy=4)
     # -i beyond where the warm-up loop stops: on convergence em() returns (em_alg.c:73-74); on the -T cap it still enters
     # its do/while, i.e. one more EM step / accelerated cycle (em_alg.c:61-88)
     run_cli("multi_admix_k4_i1000", multi, ["-a", "-k", "4", "-r", "7", "-n", "2", "-i", "1000"])
@@ -254,6 +345,9 @@ def main():
             f.write(" ".join("%.17g" % (0.25 + 0.5 * p0[k * T + 2 * l]) for k in range(K)) + "\n")
     run_cli("c1_admix_k3_PQ", c1, ["-a", "-k", "3", "-r", "1234567", "-n", "1", "-T", "200", "-P", pf, "-Q", qf])
     run_cli("c1_admix_k3_PQ_s3", c1, ["-a", "-k", "3", "-r", "1234567", "-n", "2", "-s", "3", "-P", pf, "-Q", qf])
+    with open(os.path.join(GOLD, "CLI_MANIFEST.json"), "w") as f:
+        json.dump(CLI_RECORD, f, indent=1, sort_keys=True)
+        f.write("\n")
 
 
 if __name__ == "__main__":

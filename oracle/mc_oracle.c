@@ -140,6 +140,10 @@ double *mco_model_p(mco_model *m, int s) { return m->p[s]; }
 double *mco_model_q(mco_model *m, int s) { return m->q[s]; }
 double *mco_model_sik(mco_model *m) { return m->sik; }
 double *mco_model_u_p(mco_model *m, int j) { return m->u_p[j]; }
+double *mco_model_u_q(mco_model *m, int j) { return m->u_q[j]; }
+double *mco_model_v_q(mco_model *m, int j) { return m->v_q[j]; }
+int mco_model_delta_index(const mco_model *m) { return m->delta_index; }
+void mco_model_set_delta_index(mco_model *m, int delta_index) { m->delta_index = delta_index; }	/* model::delta_index (em_alg.c:1171) */
 double *mco_model_v_p(mco_model *m, int j) { return m->v_p[j]; }
 int mco_model_q_len(const mco_model *m) { return m->nq; }
 double mco_model_logL(const mco_model *m) { return m->logL; }

@@ -62,6 +62,10 @@ double *mco_model_q(mco_model *m, int slot);
 double *mco_model_sik(mco_model *m);	/* [I][K]: sum_lm d_iklm of the last E-step (admixture) or vik (mixture) */
 double *mco_model_u_p(mco_model *m, int j);
 double *mco_model_v_p(mco_model *m, int j);
+double *mco_model_u_q(mco_model *m, int j);	/* eta parts of the secant pairs (u_etaik / u_etak, v_etaik / v_etak) */
+double *mco_model_v_q(mco_model *m, int j);
+int mco_model_delta_index(const mco_model *m);
+void mco_model_set_delta_index(mco_model *m, int delta_index);	/* with the secants: the state of a QN run with q > 1 between cycles */
 int mco_model_q_len(const mco_model *m);
 void mco_model_reset(mco_model *m);	/* initialize_model() state reset, rnd_init.c:58-71 + multiclust.c:518-524 */
 double mco_model_logL(const mco_model *m);

@@ -192,6 +192,7 @@ int main(int argc, const char **argv)
 	man_hex("lower_bound_hex", opt->lower_bound); man_dbl("lower_bound", opt->lower_bound);
 	man_dbl("abs_error", opt->abs_error); man_dbl("rel_error", opt->rel_error);
 	man_int("max_iter", opt->max_iter);
+	man_int("adjust_step", opt->adjust_step);
 	man_int("no_parameters", mod->no_parameters);
 
 	/* ---- data ---- */
@@ -321,6 +322,9 @@ int main(int argc, const char **argv)
 		 * <= 1 (stride 1: every cycle), so that each cycle of the whole run can be checked from the reference's own state */
 		const int st_stride = getenv("REF_HARNESS_CYCLE_STATES") ? atoi(getenv("REF_HARNESS_CYCLE_STATES")) : 0;
 		FILE *fs = st_stride > 0 ? xopen("accel_states.f64") : NULL;
+		/* quasi-Newton with q > 1 carries the last q secant pairs from cycle to cycle: with every recorded state also
+		 * delta_index and u_j, v_j (eta part, then p part; j = 0..q-1) -> accel_secants.f64 */
+		FILE *fq = (fs && opt->q > 1) ? xopen("accel_secants.f64") : NULL;
 		int n_states = 0;
 		if (!mod->converged) do {
 			double rec[8] = {0};
@@ -335,6 +339,22 @@ int main(int argc, const char **argv)
 					for (int l = 0; l < dat->L; l++)
 						fwrite(mod->vpklm[mod->pindex][k][l], sizeof(double), dat->uniquealleles[l], fs);
 				n_states++;
+				if (fq) {
+					double di = mod->delta_index;
+					fwrite(&c, sizeof c, 1, fq);
+					fwrite(&di, sizeof di, 1, fq);
+					for (int j = 0; j < opt->q; j++)
+						for (int w = 0; w < 2; w++) {
+							if (opt->admixture && !opt->eta_constrained)
+								for (int i = 0; i < dat->I; i++)
+									fwrite((w ? mod->v_etaik : mod->u_etaik)[j][i], sizeof(double), mod->K, fq);
+							else
+								fwrite((w ? mod->v_etak : mod->u_etak)[j], sizeof(double), mod->K, fq);
+							for (int k = 0; k < mod->K; k++)
+								for (int l = 0; l < dat->L; l++)
+									fwrite((w ? mod->v_pklm : mod->u_pklm)[j][k][l], sizeof(double), dat->uniquealleles[l], fq);
+						}
+				}
 			}
 			em_2_steps(mod, dat, opt);
 			if (mod->stopped) { stop_flag = 1; break; }
@@ -385,6 +405,7 @@ int main(int argc, const char **argv)
 			}
 		} while (!stop_flag);
 		fclose(f);
+		if (fq) fclose(fq);
 		if (fs) {
 			fclose(fs);
 			man_int("accel_states", n_states);

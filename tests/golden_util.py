@@ -48,6 +48,32 @@ class Golden:
     def ilm(self):
         return self.i32("ilm.i32").reshape(self.I, self.T)
 
+    def cycle_states(self):
+        """{cycle: (q, p)}: the iterate the reference's accelerated run started that cycle from (accel_states.f64)"""
+        nq = self.I * self.K if self.indiv_q else self.K
+        rows = self.f64("accel_states.f64").reshape(-1, 1 + nq + self.K * self.T)
+        return {int(r[0]): (r[1:1 + nq].reshape(self.I, self.K) if self.indiv_q else r[1:1 + nq], r[1 + nq:].reshape(self.K, self.T))
+                for r in rows}
+
+    def cycle_secants(self):
+        """{cycle: (delta_index, [(u_q, u_p, v_q, v_p) for j in range(q)])}: what a quasi-Newton run with q > 1 secant pairs
+        carries into that cycle besides the iterate (accel_secants.f64; model::delta_index and u_/v_ etaik, pklm); {} if q = 1"""
+        if not self.has("accel_secants.f64"):
+            return {}
+        nq, KT, nsec = (self.I * self.K if self.indiv_q else self.K), self.K * self.T, self.m["q"]
+        rows = self.f64("accel_secants.f64").reshape(-1, 2 + nsec * 2 * (nq + KT))
+        out = {}
+        for r in rows:
+            parts, x = [], 2
+            for _ in range(nsec):
+                four = []
+                for _w in range(2):
+                    four += [r[x:x + nq], r[x + nq:x + nq + KT].reshape(self.K, self.T)]
+                    x += nq + KT
+                parts.append(tuple(four))
+            out[int(r[0])] = (int(r[1]), parts)
+        return out
+
 
 def ulp_diff(a, b):
     """max distance in units-in-the-last-place between two float64 arrays (same sign assumed for large values)."""

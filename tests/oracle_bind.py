@@ -47,7 +47,10 @@ def _load():
     lib.mco_model_create.restype = vp
     lib.mco_model_create.argtypes = [vp, C.POINTER(Options), i32]
     lib.mco_model_free.argtypes = [vp]
-    for fn in ("mco_model_p", "mco_model_q", "mco_model_u_p", "mco_model_v_p"):
+    lib.mco_model_delta_index.argtypes = [C.c_void_p]
+    lib.mco_model_set_delta_index.argtypes = [C.c_void_p, C.c_int]
+    lib.mco_model_set_delta_index.restype = None
+    for fn in ("mco_model_p", "mco_model_q", "mco_model_u_p", "mco_model_v_p", "mco_model_u_q", "mco_model_v_q"):
         getattr(lib, fn).restype = dp
         getattr(lib, fn).argtypes = [vp, i32]
     lib.mco_model_sik.restype = dp
@@ -135,6 +138,15 @@ class Model:
 
     def v_p(self, j):
         return np.ctypeslib.as_array(lib.mco_model_v_p(self.h, j), shape=(self.K, self.data.T))
+
+    def u_q(self, j):
+        return np.ctypeslib.as_array(lib.mco_model_u_q(self.h, j), shape=(self.nq,))
+
+    def v_q(self, j):
+        return np.ctypeslib.as_array(lib.mco_model_v_q(self.h, j), shape=(self.nq,))
+
+    def set_delta_index(self, di):
+        lib.mco_model_set_delta_index(self.h, int(di))
 
     def reset(self):
         lib.mco_model_reset(self.h)

@@ -137,7 +137,7 @@ def test_accelerated_run(name):
     if g.K == 1:
         pytest.skip("K=1")
     opt, data, mod = make(g, accel_scheme=g.m["accel_scheme"], abs_error=g.m["abs_error"],
-                          rel_error=g.m["rel_error"], max_iter=g.m["max_iter"])
+                          rel_error=g.m["rel_error"], max_iter=g.m["max_iter"], adjust_step=g.m.get("adjust_step", 0))
     _set_init(g, mod)
     trace = g.f64("accel_trace.f64").reshape(-1, 8)
     # q-1 secant-collecting double steps (em_alg.c:69-72)
@@ -195,26 +195,36 @@ def test_every_accelerated_cycle_from_the_reference_state(name):
     (accel_states.f64): one accelerated_em_step of the restatement reproduces the recorded emll, step, ll, accept flag and
     the next recorded iterate bit for bit."""
     g = Golden(name)
-    opt, data, mod = make(g, accel_scheme=g.m["accel_scheme"], abs_error=g.m["abs_error"], rel_error=g.m["rel_error"])
+    opt, data, mod = make(g, accel_scheme=g.m["accel_scheme"], abs_error=g.m["abs_error"], rel_error=g.m["rel_error"],
+                          adjust_step=g.m.get("adjust_step", 0))
     trace = g.f64("accel_trace.f64").reshape(-1, 8)
-    nq = g.I * g.K if g.indiv_q else g.K
-    rows = g.f64("accel_states.f64").reshape(-1, 1 + nq + g.K * g.T)
-    states = {int(r[0]): r for r in rows}
-    assert len(states) == g.m["accel_states"]
+    states, secants = g.cycle_states(), g.cycle_secants()
+    assert len(states) == g.m["accel_states"] and (g.m["q"] == 1 or len(secants) == len(states))
     for c in sorted(states):
         if c >= len(trace):
             continue
         mod.reset()
-        mod.q(0)[...] = states[c][1:1 + nq].reshape(mod.q(0).shape)
-        mod.p(0)[...] = states[c][1 + nq:].reshape(g.K, g.T)
+        mod.q(0)[...] = states[c][0]
+        mod.p(0)[...] = states[c][1]
+        if secants:             # quasi-Newton, q > 1: the last q secant pairs and the slot the next pair goes to (em_alg.c:1171)
+            di, parts = secants[c]
+            mod.set_delta_index(di)
+            for j, (uq, up, vq, vp) in enumerate(parts):
+                mod.u_q(j)[...], mod.u_p(j)[...], mod.v_q(j)[...], mod.v_p(j)[...] = uq, up, vq, vp
         stop, (emll, s, ll, acc) = mod.accelerated_em_step()
         assert not stop and emll == trace[c, 0], c
         if trace[c, 7]:
             assert s == trace[c, 1] and ll == trace[c, 2] and acc == trace[c, 3], c
         assert mod.logL == trace[c, 5], c
         if c + 1 in states:
-            assert np.array_equal(mod.q(mod.pindex).ravel(), states[c + 1][1:1 + nq]), c
-            assert np.array_equal(mod.p(mod.pindex).ravel(), states[c + 1][1 + nq:]), c
+            assert np.array_equal(mod.q(mod.pindex), states[c + 1][0]), c
+            assert np.array_equal(mod.p(mod.pindex), states[c + 1][1]), c
+        if secants and c + 1 in secants:        # the pair this cycle collected, in the slot it went to, and the rotated index
+            di2, parts2 = secants[c + 1]
+            assert ob.lib.mco_model_delta_index(mod.h) == di2, c
+            for j, (uq, up, vq, vp) in enumerate(parts2):
+                assert np.array_equal(mod.u_q(j), uq) and np.array_equal(mod.u_p(j), up), (c, j)
+                assert np.array_equal(mod.v_q(j), vq) and np.array_equal(mod.v_p(j), vp), (c, j)
 
 
 @pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "multi_admix_k4_s2", "tetra_admix_k3", "missing_admix_k3"])
