@@ -62,6 +62,11 @@ struct mchip_context {
 	uint8_t *d_asA, *d_asS;		/* hard-partition scratch, allocated on first use */
 	uint8_t *d_initA, *d_initS;	/* genotype the hard-partition M step reads when it is not the data set itself (bootstrap) */
 	uint8_t *d_draw;		/* device-drawn partition in stream order [I][L][ploidy], padded to whole chunks */
+	/* Rand-EM candidates (mchip_init_from_allele_centers), kept from one candidate to the next and grown when needed: the
+	 * rand() % K values of a candidate's span of the stream, its center alleles [L][K], its per-locus draw offsets */
+	uint8_t *d_cand_span, *d_cand_centers;
+	unsigned long long *d_cand_off;
+	size_t cand_span_bytes, cand_loci, cand_center_bytes;
 	uint32_t *d_jump_hi, *d_jump_lo;	/* jump polynomials of the rand() stream (mchip_mstep_from_rand_partition) */
 	size_t n_jump_hi;
 	/* jump polynomials of the tiled generators (0: bootstrap data set, 1: random partition): x^(A*i), i < nA, stored [31][nA]
@@ -1344,6 +1349,8 @@ static void free_data(mchip_context *ctx)
 	dfree(ctx->d_gtA); dfree(ctx->d_gtS); dfree(ctx->d_gtC); dfree(ctx->d_asA); dfree(ctx->d_asS);
 	dfree(ctx->d_initA); dfree(ctx->d_initS);
 	dfree(ctx->d_draw); dfree(ctx->d_jump_hi); dfree(ctx->d_jump_lo);
+	dfree(ctx->d_cand_span); dfree(ctx->d_cand_centers); dfree(ctx->d_cand_off);
+	ctx->cand_span_bytes = ctx->cand_loci = ctx->cand_center_bytes = 0;
 	ctx->n_jump_hi = 0;
 	for (int x = 0; x < 2; x++) { dfree(ctx->lat[x].d_i); dfree(ctx->lat[x].d_r); ctx->lat[x].nA = 0; }
 	dfree(ctx->d_part_slabs);
@@ -2400,46 +2407,60 @@ int mchip_init_from_allele_centers(mchip_context *ctx, const uint8_t *centers, c
 	if (rc) return rc;
 	if (!draw_offset || !window) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
-	const size_t n = (size_t)ctx->I * ctx->L * ctx->ploidy;
-	/* rand() % K for the candidate's whole span of the stream (center draws included: the host knows which draws are whose) */
-	scoped_dev<uint8_t> d_span, d_cen, d_raw;
-	scoped_dev<unsigned long long> d_off;
+	/* rand() % K for the candidate's whole span of the stream (center draws included: the host knows which draws are whose).
+	 * No allocation per candidate: the span, centers and offsets live in the context (grown when a candidate needs more), the
+	 * assignment goes to the stream-order scratch buffer -- a hipFree would synchronise the whole device and stall the other
+	 * --streams workers, n_rand_em_init times per initialisation */
+	if ((rc = stream_buffer(ctx))) return rc;
+	uint8_t *d_raw = ctx->d_draw;
 	rng_window base;
 	size_t n_chunks = 0, n_blocks = 0;
+	auto grow = [&](void **p, size_t *have, size_t want) -> hipError_t {
+		if (*have >= want) return hipSuccess;
+		if (*p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*p); *p = nullptr; *have = 0; }
+		const hipError_t e = hipMalloc(p, want);
+		if (e == hipSuccess) *have = want;
+		return e;
+	};
 	if (n_draws) {
 		if ((rc = rng_stream_setup(ctx, window, (size_t)n_draws, &base, &n_chunks, &n_blocks))) return rc;
-		HIPCHK(d_span.alloc(n_chunks * RNG_CHUNK));
+		HIPCHK(grow((void **)&ctx->d_cand_span, &ctx->cand_span_bytes, n_chunks * RNG_CHUNK + n_chunks * RNG_CHUNK / 8));
 		if (ctx->K == 1) {
-			HIPCHK(hipMemsetAsync(d_span, 0, n_chunks * RNG_CHUNK, ctx->stream));
+			HIPCHK(hipMemsetAsync(ctx->d_cand_span, 0, n_chunks * RNG_CHUNK, ctx->stream));
 		} else {
 			uint32_t magic, shift;
 			mod_k_magic(ctx->K, &magic, &shift);
 			hipLaunchKernelGGL(k_draw_partition, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, base, ctx->d_jump_hi,
-					   ctx->d_jump_lo, n_chunks, (uint32_t)ctx->K, magic, shift, (uint32_t *)d_span.p);
+					   ctx->d_jump_lo, n_chunks, (uint32_t)ctx->K, magic, shift, (uint32_t *)ctx->d_cand_span);
 		}
 	} else {
-		HIPCHK(d_span.alloc(16));	/* no copy draws: never read */
+		HIPCHK(grow((void **)&ctx->d_cand_span, &ctx->cand_span_bytes, 16));	/* no copy draws: never read */
 	}
 	/* every offset must leave room for the locus's copies inside the span: a locus reads at most I*ploidy draws */
 	for (int l = 0; l < ctx->L; l++)
 		if (draw_offset[l] > n_draws) return fail(ctx, MCHIP_ERR_INVALID, "draw offset beyond the stream span%s", nullptr);
-	HIPCHK(d_cen.alloc((size_t)ctx->L * ctx->K));
-	HIPCHK(d_off.alloc((size_t)ctx->L));
-	HIPCHK(d_raw.alloc(n));
+	HIPCHK(grow((void **)&ctx->d_cand_centers, &ctx->cand_center_bytes, (size_t)ctx->L * ctx->K));
+	{
+		size_t have = ctx->cand_loci * sizeof(unsigned long long);
+		HIPCHK(grow((void **)&ctx->d_cand_off, &have, (size_t)ctx->L * sizeof(unsigned long long)));
+		ctx->cand_loci = have / sizeof(unsigned long long);
+	}
+	uint8_t *d_span = ctx->d_cand_span, *d_cen = ctx->d_cand_centers;
+	unsigned long long *d_off = ctx->d_cand_off;
 	HIPCHK(hipMemcpyAsync(d_cen, centers, (size_t)ctx->L * ctx->K, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(d_off, draw_offset, sizeof(uint64_t) * (size_t)ctx->L, hipMemcpyHostToDevice, ctx->stream));
 	int *d_bad = bad_flag(ctx);
 	HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
 	hipLaunchKernelGGL(k_assign_by_centers, dim3(nblk((size_t)ctx->L)), dim3(256), 0, ctx->stream,
-			   ctx->init_geno_set ? ctx->d_initA : ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, ctx->K, d_cen.p, d_off.p, d_span.p,
-			   (unsigned long long)n_draws, d_raw.p, d_bad);
+			   ctx->init_geno_set ? ctx->d_initA : ctx->d_gtA, ctx->I, ctx->L, ctx->ploidy, ctx->K, d_cen, d_off, d_span,
+			   (unsigned long long)n_draws, d_raw, d_bad);
 	HIPCHK(hipGetLastError());
 	int bad = 0;
 	HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	if (bad) return fail(ctx, MCHIP_ERR_INVALID, "allele-center draws run past the stream span: offsets do not match the genotype held%s", nullptr);
 	rc = partition_mstep(ctx, d_raw, to, 1);
-	(void)hipStreamSynchronize(ctx->stream);	/* the temporaries go out of scope */
+	(void)hipStreamSynchronize(ctx->stream);	/* centers / draw_offset are the caller's: uploaded by now */
 	return rc;
 }
 

@@ -131,6 +131,9 @@ int mc_randem_initialize(const mc_options *opt, const mc_data *dat, mc_model *mo
  * A jump for the random allele partition; for Rand-EM and the mixture model the number of draws depends on the draws
  * themselves (center retries) and on the data (copies that match no center), so the host-side walk is replayed. */
 int mc_skip_initializations(const mc_options *opt, const mc_data *dat, mc_model *mod, mc_rng *rng, int n);
+/* starts[u], u = 0..n_units: the generator at the start of unit u of a sharded run (one walk over the units; `mod` supplies K and
+ * holds the allele-count cache of the Rand-EM walk: a zeroed mc_model with K set will do, mc_init_cache_free() afterwards) */
+int mc_unit_starts(const mc_options *opt, const mc_data *dat, mc_model *mod, const mc_rng *base, int n_units, mc_rng *starts);
 void mc_init_cache_free(mc_model *mod);
 
 void mc_em(const mc_options *opt, const mc_data *dat, mc_model *mod);			/* em_alg.c:44 */

@@ -163,7 +163,9 @@ static void rng_skip(mc_rng *rng, uint64_t n)
 static uint64_t walk_allele_centers(const mc_data *dat, const init_cache *c, int K, mc_rng *rng, uint8_t *centers, uint64_t *offsets)
 {
 	const uint64_t copies = (uint64_t)dat->I * dat->ploidy;
-	uint64_t pos = 0;
+	uint64_t pos = 0, pending = 0;	/* draws the copies of earlier loci consume, not yet taken off the generator: only a locus
+					 * that draws its centers needs the generator in place, so the skips of the loci between two such
+					 * loci (every locus when K exceeds the allele counts: config 4) are made in one step */
 	int center[K];
 	if (K == 1) {		/* rnd_init.c:505-510: every copy to cluster 0, nothing drawn */
 		if (centers) memset(centers, 0xFF, (size_t)dat->L);
@@ -176,6 +178,8 @@ static uint64_t walk_allele_centers(const mc_data *dat, const init_cache *c, int
 			for (int k = 0; k < M; k++) center[k] = k;
 			for (int k = M; k < K; k++) center[k] = -1;
 		} else {
+			rng_skip(rng, pending);
+			pending = 0;
 			for (int k = 0; k < K; k++) {	/* K distinct slots by rejection, as above (rnd_init.c:530-548) */
 				int pick = mc_rand(rng) % M;
 				pos++;
@@ -190,9 +194,10 @@ static uint64_t walk_allele_centers(const mc_data *dat, const init_cache *c, int
 		for (int k = 0; k < K && center[k] >= 0; k++) matched += c->count[c->toff[l] + center[k]];
 		if (centers) for (int k = 0; k < K; k++) centers[(size_t)l * K + k] = center[k] < 0 ? 0xFF : (uint8_t)center[k];
 		if (offsets) offsets[l] = pos;
-		rng_skip(rng, copies - matched);
+		pending += copies - matched;
 		pos += copies - matched;
 	}
+	rng_skip(rng, pending);
 	return pos;
 }
 
@@ -251,6 +256,22 @@ static int randem_mixture(const mc_options *opt, const mc_data *dat, mc_model *m
 int mc_randem_initialize(const mc_options *opt, const mc_data *dat, mc_model *mod, mc_rng *rng)
 {
 	return opt->admixture ? randem_admixture(opt, dat, mod, rng) : randem_mixture(opt, dat, mod, rng);
+}
+
+/* Where every unit of a sharded run starts in the stream: starts[u] = the generator after u initialisations, u = 0..n_units (the
+ * last entry is where the serial program stands afterwards).  One walk over the units; workers that each replayed the units
+ * before theirs (mc_skip_initializations) did O(units^2) walks between them when the draws are data dependent (Rand-EM). */
+int mc_unit_starts(const mc_options *opt, const mc_data *dat, mc_model *mod, const mc_rng *base, int n_units, mc_rng *starts)
+{
+	mc_rng rng = *base;
+	for (int u = 0; u <= n_units; u++) {
+		starts[u] = rng;
+		if (u < n_units) {
+			const int rc = mc_skip_initializations(opt, dat, mod, &rng, 1);
+			if (rc) return rc;
+		}
+	}
+	return 0;
 }
 
 int mc_skip_initializations(const mc_options *opt, const mc_data *dat, mc_model *mod, mc_rng *rng, int n)

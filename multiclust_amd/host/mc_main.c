@@ -395,8 +395,7 @@ typedef struct shard_worker {
 	const mc_data *md;
 	int K, index, n_dev, n_units, want_params;
 	const mc_simulation *sim;	/* bootstrap replicate generated on the device, or NULL */
-	mc_rng base;			/* the serial stream's state where this K's initialisations begin */
-	mc_rng rng_end;			/* set by the worker that fitted the last unit: the stream after it */
+	const mc_rng *starts;		/* [n_units + 1]: the serial stream's state at the start of every unit (and after the last) */
 	uint64_t draws;
 	mc_unit_result *res;		/* [n_units], shared: worker d writes rows u = d, d + n_dev, ... */
 	double best_logL;
@@ -415,12 +414,9 @@ static void *shard_main(void *arg)
 	if ((w->rc = w->sim ? mc_model_create_simulated(&mod, &w->o->em, w->md, w->K, device, w->sim)
 			    : mc_model_create(&mod, &w->o->em, w->md, w->K, device))) return NULL;
 	const clock_t start = clock();
-	/* unit u starts where the serial stream stands after u initialisations: a jump for the random allele partition, a replay
-	 * of the host-side draws for Rand-EM; an initialisation leaves the stream at the next unit's start */
-	mc_rng rng = w->base;
-	if ((w->rc = mc_skip_initializations(&w->o->em, w->md, mod, &rng, w->index))) { mc_model_free(mod); return NULL; }
+	/* unit u starts where the serial stream stands after u initialisations (w->starts, walked once by the caller) */
 	for (int u = w->index; u < w->n_units; u += w->n_dev) {
-		if (u != w->index && (w->rc = mc_skip_initializations(&w->o->em, w->md, mod, &rng, w->n_dev - 1))) break;
+		mc_rng rng = w->starts[u];
 		mc_reset_model_state(mod);
 		mod->start = start;
 		if ((w->rc = mc_initialize_model(&w->o->em, w->md, mod, &rng))) break;
@@ -440,7 +436,6 @@ static void *shard_main(void *arg)
 			w->best_logL = mod->logL;
 			w->best_unit = u;
 		}
-		if (u == w->n_units - 1) w->rng_end = rng;	/* where the serial stream stands after all units */
 	}
 	mc_model_free(mod);
 	return NULL;
@@ -460,18 +455,28 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 	mc_unit_result *res = calloc((size_t)n_units, sizeof *res);
 	double **tab = calloc((size_t)n_gpus, sizeof *tab);
 	int *count_K = calloc((size_t)K, sizeof *count_K), rc = 0;
-	if (!w || !th || !res || !tab || !count_K) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+	mc_rng *starts = calloc((size_t)n_units + 1, sizeof *starts);
+	if (!w || !th || !res || !tab || !count_K || !starts) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+	{	/* where each unit starts in the rand() stream: one walk (a jump per unit for the random allele partition, the host-side
+		 * replay of the center draws for Rand-EM), instead of every worker replaying the units before its own */
+		mc_model walker;
+		memset(&walker, 0, sizeof walker);
+		walker.K = K;
+		rc = mc_unit_starts(&o->em, md, &walker, &st->rng, n_units, starts);
+		mc_init_cache_free(&walker);
+		if (rc) goto DONE;
+	}
 	for (int x = 0; x < n_dev; x++) {
 		w[x].o = o; w[x].d = d; w[x].md = md; w[x].K = K; w[x].index = x; w[x].n_dev = n_dev; w[x].n_units = n_units;
 		w[x].want_params = keep_mle || (!bootstrap && o->write_files);
 		w[x].sim = sim;
-		w[x].base = st->rng; w[x].draws = mc_draws_per_init(&o->em, md, K); w[x].res = res;
+		w[x].starts = starts; w[x].draws = mc_draws_per_init(&o->em, md, K); w[x].res = res;
 		if (pthread_create(&th[x], NULL, shard_main, &w[x])) { shard_main(&w[x]); th[x] = 0; }
 	}
 	for (int x = 0; x < n_dev; x++) if (th[x]) pthread_join(th[x], NULL);
 	for (int x = 0; x < n_dev; x++) if (w[x].rc) rc = w[x].rc;
 	if (rc) goto DONE;
-	st->rng = w[(n_units - 1) % n_dev].rng_end;	/* where the serial stream stands after these initialisations */
+	st->rng = starts[n_units];	/* where the serial stream stands after these initialisations */
 
 	/* the one exchange: every device's result table holds the rows its workers fitted; an RCCL all-reduce (sum)
 	 * completes them all */
@@ -521,7 +526,7 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 DONE:
 	if (w) for (int x = 0; x < n_dev; x++) { free(w[x].q); free(w[x].p); free(w[x].sik); }
 	if (tab) for (int x = 0; x < n_gpus; x++) free(tab[x]);
-	free(w); free(th); free(res); free(tab); free(count_K);
+	free(w); free(th); free(res); free(tab); free(count_K); free(starts);
 	return rc;
 }
 
