@@ -84,8 +84,16 @@ exp-k8: $(LIB)/libmulticlust_hip.so
 	$(HIPCC) --offload-arch=$(ARCH) --offload-compress -shared -fPIC -o scripts/exp/libmulticlust_hip_$(EXPNAME).so \
 		$(filter-out $(OBJ)/mchip_k8.o,$(OBJ)/mchip.o $(OBJ)/mchip_comm.o $(KOBJ)) build/exp/mchip_k8_$(EXPNAME).o -ldl
 
+# the same for any K: `make exp-k EXPK=40 EXPNAME=k40s4 EXPFLAGS=-DMCHIP_COL_SPLIT4_ABOVE=24`
+EXPK ?= 8
+exp-k: $(LIB)/libmulticlust_hip.so
+	@mkdir -p build/exp scripts/exp
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) $(EXPFLAGS) -DMCHIP_K=$(EXPK) -c multiclust_amd/csrc/mchip_kernels_k.hip -o build/exp/mchip_k$(EXPK)_$(EXPNAME).o
+	$(HIPCC) --offload-arch=$(ARCH) --offload-compress -shared -fPIC -o scripts/exp/libmulticlust_hip_$(EXPNAME).so \
+		$(filter-out $(OBJ)/mchip_k$(EXPK).o,$(OBJ)/mchip.o $(OBJ)/mchip_comm.o $(KOBJ)) build/exp/mchip_k$(EXPK)_$(EXPNAME).o -ldl
+
 clean:
 	rm -rf build $(LIB)/*.so $(BIN) scripts/micro/fp64_micro scripts/micro/op_cost scripts/micro/lds_valu scripts/micro/vgpr_banks scripts/exp/*.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle micro exp-scatter exp-k52 exp-k8 clean
+.PHONY: all oracle micro exp-scatter exp-k52 exp-k8 exp-k clean

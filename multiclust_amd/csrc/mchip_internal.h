@@ -44,13 +44,45 @@ constexpr int mchip_qblock(int) { return MCHIP_QBLOCK; }
 #else
 constexpr int mchip_qblock(int K) { return K > 48 ? 2 * MCHIP_QBLOCK : MCHIP_QBLOCK; }
 #endif
+/* Column pass: lanes that share one allele column (each holds a range of k of P_.c and of the N-side accumulators; the q rows of
+ * the individuals come from LDS instead of scalar registers, the partial dot products are combined across the lanes).  One lane
+ * holds 4K doubles and wants 2K scalar registers: neither fits at large K (67 SGPRs spilled at K = 64: 14.0 ms at the 5 000 x
+ * 50 000 shape).  Measured (profiles/r03_k_sweep.txt): two lanes per column win from K = 37 (K = 38: 3.34 ms with one lane; K = 40: 2.91 against 3.06 ms) to K = 64
+ * (4.83 against 13.95 ms; K = 48: 3.77 against 5.45 ms) and lose at K = 36 (2.64 against 2.11 ms); four lanes per column lose to
+ * two at every K tried (K = 48: 4.12 ms, K = 64: 5.50 ms): every lane repeats the count extraction and the reciprocal. */
+#ifndef MCHIP_COL_SPLIT2_ABOVE
+#define MCHIP_COL_SPLIT2_ABOVE 36
+#endif
+#ifndef MCHIP_COL_SPLIT4_ABOVE
+#define MCHIP_COL_SPLIT4_ABOVE 9999	/* experiments only */
+#endif
+constexpr int mchip_col_split(int K) { return K > MCHIP_COL_SPLIT4_ABOVE ? 4 : (K > MCHIP_COL_SPLIT2_ABOVE ? 2 : 1); }
 /* LDS row stride of the staged P tiles in doubles: rows stay 16-byte aligned and hold the lanes' k ranges (each padded to an even
  * count); a stride of 128 or 256 bytes would put the rows of a locus on the same banks (64 banks x 4 bytes), so multiples of 16
  * get two doubles of padding */
+/* LDS doubles between the lane parts of a staged row (sparse individual pass with a lane split): each part's KSP doubles, plus
+ * padding where two parts would start on the same banks (64 banks x 4 bytes, a 16-byte read covers 4): KSP = 16 (K = 57 ... 64)
+ * put parts 0 / 2 and 1 / 3 on the same banks and cost the S-side pass 40 % (6.0 against 4.2 ms at K = 56) */
+constexpr bool mchip_parts_conflict(int split, int stride)
+{
+	for (int a = 0; a < split; a++)
+		for (int b = a + 1; b < split; b++) {
+			const int d = (2 * stride * (b - a)) % 64;
+			if (d < 4 || d > 60) return true;
+		}
+	return false;
+}
+constexpr int mchip_ind_pstride(int K)
+{
+	const int split = mchip_ind_split(K);
+	int stride = ((((K + split - 1) / split) + 1) & ~1);
+	while (split > 1 && mchip_parts_conflict(split, stride)) stride += 2;
+	return stride;
+}
 constexpr int mchip_kp(int K)
 {
 	const int split = mchip_ind_split(K);
-	const int per_lane = ((((K + split - 1) / split) + 1) & ~1) * split;
+	const int per_lane = mchip_ind_pstride(K) * split;
 	const int base = per_lane > ((K + 1) & ~1) ? per_lane : ((K + 1) & ~1);
 	return base + ((base % 16 == 0) ? 2 : 0);
 }

@@ -324,6 +324,135 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 	}
 }
 
+/* ---------------------------------------------------------------- column pass on packed counts, k range split over CSPLIT lanes
+ * K >= 37: CSPLIT = 2 adjacent lanes = one allele column, lane part s holds k in [s CKS, (s+1) CKS) of P_.c and of the
+ * accumulators.  The q rows of one dword's worth of individuals (16 at 2 bits per count, 8 at 4) are staged in LDS
+ * (double-buffered: the next batch waits in registers while this one is computed); a lane reads its part of a row with
+ * ds_read_b128 (the parts of a row sit an odd number of 16-byte units apart: distinct banks), forms its partial dot product, and
+ * the lanes of a column add their partials with DPP exchanges (every lane ends on the same bits: a + b = b + a at each level).
+ * One reciprocal per cell. */
+constexpr int CSPLIT = mchip_col_split(K);
+constexpr int CKS = (K + CSPLIT - 1) / CSPLIT;		/* k per lane part */
+constexpr int CKSE = (CKS + 1) & ~1;			/* rounded up to whole 16-byte reads (the padding multiplies p = 0) */
+/* LDS doubles per (individual, part): the parts of a row must not start on the same banks (64 banks x 4 bytes; a 16-byte read
+ * covers 4): K = 60 with a stride of 32 doubles = 256 bytes put both parts on banks 0-3 and cost 25 % */
+constexpr int cqs_stride(int n) { return ((2 * n) % 64 < 4 || (2 * n) % 64 > 60) ? n + 2 : n; }
+constexpr int CQS = cqs_stride(CKSE + 2);
+
+template <int CTRL> __device__ __forceinline__ double quad_exchange(double v)
+{
+	return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false),
+				__builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false));
+}
+/* sum over the four lanes of a quad: v + (the lane whose index differs in bit 0), then the same for bit 1
+ * (quad_perm [1,0,3,2] = 0xB1 and [2,3,0,1] = 0x4E) */
+__device__ __forceinline__ double quad_sum(double v)
+{
+	v += quad_exchange<0xB1>(v);
+	if (CSPLIT == 4) v += quad_exchange<0x4E>(v);
+	return v;
+}
+
+template <int BITS, bool SAFE>
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts_split(mchip_pass_args a)
+{
+	static_assert(CSPLIT == 4 || CSPLIT == 2 || CSPLIT == 1, "quad exchange");
+	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
+	constexpr int PERWORD = 32 / BITS;		/* individuals per dword = per staged batch */
+	constexpr int G = 4 * PERWORD;
+	constexpr unsigned MASK = (1u << BITS) - 1u;
+	constexpr int ROW = CSPLIT * CQS;		/* LDS doubles per individual */
+	constexpr int NST = (PERWORD * K + MCHIP_BLOCK - 1) / MCHIP_BLOCK;	/* staged doubles per thread */
+	__shared__ __attribute__((aligned(16))) double qs[2][PERWORD * ROW];
+	const int part = threadIdx.x % CSPLIT, k0 = part * CKS;
+	const int c_raw = blockIdx.x * (MCHIP_BLOCK / CSPLIT) + threadIdx.x / CSPLIT;
+	const bool valid = c_raw < a.T;
+	const int c = valid ? c_raw : a.T - 1;
+	double p[CKSE], acc[CKSE];
+#pragma unroll
+	for (int k = 0; k < CKSE; k++) {
+		p[k] = (k < CKS && k0 + k < K) ? a.P[(size_t)c * K + k0 + k] : 0.0;
+		acc[k] = 0.0;
+	}
+	const int i0 = blockIdx.y * a.ichunk;		/* multiple of G */
+	const int i1 = min(a.I, i0 + a.ichunk);
+	const int g_end = (i1 + G - 1) / G;
+	/* the padding slots multiply p = 0: they must hold finite values, not whatever the last kernel left in LDS */
+	for (int x = threadIdx.x; x < 2 * PERWORD * ROW; x += MCHIP_BLOCK) qs[0][x] = 0.0;
+	__syncthreads();
+	auto q_address = [&](int x, int ibase) __attribute__((always_inline)) {	/* element x of a batch: individual x / K, cluster x % K */
+		const int j = x / K, k = x % K;
+		return a.Q + (size_t)min(ibase + j, a.I - 1) * a.qstride + k;
+	};
+	auto q_slot = [&](int x) __attribute__((always_inline)) { const int j = x / K, k = x % K; return j * ROW + (k / CKS) * CQS + (k % CKS); };
+	for (int y = 0; y < NST; y++) {
+		const int x = threadIdx.x + y * MCHIP_BLOCK;
+		if (x < PERWORD * K) qs[0][q_slot(x)] = *q_address(x, i0);
+	}
+	const uint4 *gt = reinterpret_cast<const uint4 *>(a.gtC);
+	uint4 w = gt[(size_t)(i0 / G) * a.T + c];
+	__syncthreads();
+	int buf = 0;
+	for (int g = i0 / G; g < g_end; g++) {
+		const uint4 wn = gt[(size_t)min(g + 1, g_end - 1) * a.T + c];	/* prefetch (clamped) */
+#pragma unroll 1
+		for (int wi = 0; wi < 4; wi++) {
+			const unsigned word = (wi == 0) ? w.x : (wi == 1) ? w.y : (wi == 2) ? w.z : w.w;
+			const int ibase = g * G + wi * PERWORD;
+			if (ibase >= i1) break;		/* block-uniform: the remaining batches of the chunk's last word are empty */
+			/* the next batch's q rows: requested now, stored behind the arithmetic */
+			const int inext = ibase + PERWORD;
+			const bool more = inext < i1;	/* block-uniform */
+			double st[NST];
+			if (more) {
+#pragma unroll
+				for (int y = 0; y < NST; y++) {
+					const int x = threadIdx.x + y * MCHIP_BLOCK;
+					st[y] = *q_address(min(x, PERWORD * K - 1), inext);
+				}
+			}
+			const double *rowp = &qs[buf][part * CQS];
+#pragma unroll 1
+			for (int j = 0; j < PERWORD; j++) {
+				if (ibase + j >= i1) break;	/* wave-uniform; padded individuals have zero counts anyway */
+				const double2 *qr = reinterpret_cast<const double2 *>(rowp + j * ROW);
+				double q[CKSE];
+#pragma unroll
+				for (int k = 0; k < CKSE / 2; k++) {
+					const double2 v = qr[k];
+					q[2 * k] = v.x;
+					q[2 * k + 1] = v.y;
+				}
+				double t = q[0] * p[0];
+#pragma unroll
+				for (int k = 1; k < CKSE; k++) t = __builtin_fma(q[k], p[k], t);
+				t = quad_sum(t);
+				const double n = (double)((word >> (BITS * j)) & MASK);
+				/* SAFE: t may be 0 where n = 0 (projection off: a column whose P is 0 for every k) */
+				const double r = SAFE ? ((n != 0.0) ? n * rcp_full(t) : 0.0) : n * rcp_full(t);
+#pragma unroll
+				for (int k = 0; k < CKSE; k++) acc[k] = __builtin_fma(q[k], r, acc[k]);
+			}
+			if (more) {
+#pragma unroll
+				for (int y = 0; y < NST; y++) {
+					const int x = threadIdx.x + y * MCHIP_BLOCK;
+					if (x < PERWORD * K) qs[buf ^ 1][q_slot(x)] = st[y];
+				}
+			}
+			__syncthreads();	/* the next batch is complete, this one may be overwritten */
+			buf ^= 1;
+		}
+		w = wn;
+	}
+	if (valid) {
+		double *out = a.Apart + ((size_t)blockIdx.y * a.T + c) * K + k0;
+#pragma unroll
+		for (int k = 0; k < CKS; k++)
+			if (k0 + k < K) out[k] = acc[k];
+	}
+}
+
 /* ---------------------------------------------------------------- individual pass */
 constexpr int QBLOCK = mchip_qblock(K);
 
@@ -400,7 +529,10 @@ constexpr int SPLIT = mchip_ind_split(K);
 constexpr int KS = (K + SPLIT - 1) / SPLIT;
 constexpr int KSP = SPLIT == 1 ? K : ((KS + 1) & ~1);	/* doubles a lane works on */
 constexpr int KGP = SPLIT == 1 ? KP / 2 : KSP / 2;	/* 16-byte LDS reads per gathered row part */
-static_assert(SPLIT * ((KS + 1) & ~1) <= KP || SPLIT == 1, "row stride holds every lane's range");
+constexpr int PSTR = mchip_ind_pstride(K);		/* LDS doubles from one lane part of a row to the next (KSP, or padded: bank conflicts) */
+/* where cluster k of a staged row sits in LDS */
+__device__ __forceinline__ constexpr int lds_k(int k) { return SPLIT == 1 ? k : (k / KSP) * PSTR + (k % KSP); }
+static_assert(SPLIT * PSTR <= KP || SPLIT == 1, "row stride holds every lane's range");
 
 /* sum over the SPLIT adjacent lanes of an individual; every lane ends with the same bits (a + b = b + a at every level) */
 __device__ __forceinline__ double split_sum(double v)
@@ -429,8 +561,16 @@ __device__ __forceinline__ void rescale(double &prod, int &ex)
  * bound by the LDS gather, the second by FP64 issue, and one kernel overlaps some of the two: 2.78-2.88 ms against 1.84 + 1.15
  * at config 3 (scripts/diag/dual.sh).  Tetraploid data loses (1.53 against 0.90 + 0.55 ms at config 5's shape: 170 registers,
  * three waves per SIMD): not instantiated */
+/* minimum waves per SIMD the register allocation has to leave room for.  K = 57 ... 64 (four lanes per individual, 16 doubles of
+ * q, of the sums and of each gathered row per lane): left alone the diploid S-side instance takes 174 registers = two waves per
+ * SIMD, where K = 56 runs three on 150; held to three waves it spills a handful of registers to scratch in the block head
+ * and runs 5.3-5.5 -> 4.3-4.6 ms (profiles/r03_k_sweep.txt) */
+constexpr int sparse_min_waves(int PL, bool ACCUM)
+{
+	return MCHIP_SPARSE_WAVES > 1 ? MCHIP_SPARSE_WAVES : ((SPLIT == 4 && KSP == 16 && PL == 2 && ACCUM) ? 3 : 1);
+}
 template <int PL, bool ACCUM, bool SAFE, bool NOMISS, bool DUAL = false>
-__global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_sparse(mchip_pass_args a)
+__global__ __launch_bounds__(QBLOCK, sparse_min_waves(PL, ACCUM)) void k_individual_sparse(mchip_pass_args a)
 {
 	static_assert(!DUAL || (ACCUM && !SAFE && PL == 2), "dual pass: ACCUM, shared reciprocals, diploid");
 	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
@@ -448,7 +588,8 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 #endif
 	static_assert(!DUAL || SPLIT == 1, "dual pass: one lane per individual");
 	const int part = SPLIT == 1 ? 0 : (int)(threadIdx.x % SPLIT);	/* which k range this lane holds */
-	const int k0 = part * KSP;
+	const int k0 = part * KSP;		/* this lane's first cluster */
+	const int kl0 = part * PSTR;		/* ... and where its part of a staged row starts in LDS */
 	const int i_raw = blockIdx.x * (QBLOCK / SPLIT) + threadIdx.x / SPLIT;
 	const bool active = i_raw < a.I;
 	const int i = active ? i_raw : a.I - 1;
@@ -484,8 +625,8 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 		const int c_lo = E[0], c_hi = E[8];
 		const int nel = (c_hi - c_lo) * K;
 		for (int x = threadIdx.x; x < nel; x += QBLOCK) {
-			lds[(x / K) * KP + (x % K)] = a.P[(size_t)c_lo * K + x];
-			if (DUAL) lds2[(x / K) * KP + (x % K)] = a.P2[(size_t)c_lo * K + x];
+			lds[(x / K) * KP + lds_k(x % K)] = a.P[(size_t)c_lo * K + x];
+			if (DUAL) lds2[(x / K) * KP + lds_k(x % K)] = a.P2[(size_t)c_lo * K + x];
 		}
 	}
 	geno_group<PL> g, gn;
@@ -520,8 +661,8 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 				}
 			} else {
 				for (int x = threadIdx.x; x < nel_next; x += QBLOCK) {
-					dst[(x / K) * KP + (x % K)] = src[x];
-					if (DUAL) dst2[(x / K) * KP + (x % K)] = src2[x];
+					dst[(x / K) * KP + lds_k(x % K)] = src[x];
+					if (DUAL) dst2[(x / K) * KP + lds_k(x % K)] = src2[x];
 				}
 			}
 		}
@@ -546,7 +687,7 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 					const unsigned mm = miss[b] ? 0u : mraw;
 					row[b] = (unsigned)base + mm;
 					/* 16-byte LDS reads (ds_read_b128): twice the bytes per LDS cycle of ds_read2_b64 */
-					const double2 *pr = reinterpret_cast<const double2 *>(tile + (size_t)(base + (int)mm) * KP + k0);
+					const double2 *pr = reinterpret_cast<const double2 *>(tile + (size_t)(base + (int)mm) * KP + kl0);
 #pragma unroll
 					for (int k = 0; k < KGP; k++) {
 						const double2 v = pr[k];
@@ -636,7 +777,7 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 					const unsigned mraw = g.copy(j, bb, pl);
 					const bool miss = (mraw == MCHIP_MISSING) || !active;
 					const unsigned mm = miss ? 0u : mraw;
-					const double *pr = tile + (size_t)(base + (int)mm) * KP + k0;
+					const double *pr = tile + (size_t)(base + (int)mm) * KP + kl0;
 					double pc[KSP];
 #pragma unroll
 					for (int k = 0; k < KSP; k++) pc[k] = pr[k];
@@ -680,8 +821,8 @@ __global__ __launch_bounds__(QBLOCK, MCHIP_SPARSE_WAVES) void k_individual_spars
 #pragma unroll
 			for (int s2 = 0; s2 < STAGE; s2++) {
 				const int x = threadIdx.x + s2 * QBLOCK;
-				if (x < nel_next) dst[(x / K) * KP + (x % K)] = stage[s2];
-				if constexpr (DUAL) { if (x < nel_next) dst2[(x / K) * KP + (x % K)] = stage2[s2]; }
+				if (x < nel_next) dst[(x / K) * KP + lds_k(x % K)] = stage[s2];
+				if constexpr (DUAL) { if (x < nel_next) dst2[(x / K) * KP + lds_k(x % K)] = stage2[s2]; }
 			}
 		}
 		g = gn;
@@ -1113,6 +1254,16 @@ inline dim3 sparse_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK / 
  * the column pass also produces logL and the individual pass loops over every allele of every locus. */
 void launch_accum_p(const mchip_pass_args &a, hipStream_t s)
 {
+	if constexpr (CSPLIT > 1) {
+		if (a.sparse && a.count_bits && !getenv("MCHIP_NO_COL_SPLIT")) {
+			const dim3 grid((a.T + MCHIP_BLOCK / CSPLIT - 1) / (MCHIP_BLOCK / CSPLIT), a.n_ichunks);
+			if (a.count_bits == 2 && a.safe_rcp) hipLaunchKernelGGL((k_column_counts_split<2, true>), grid, dim3(MCHIP_BLOCK), 0, s, a);
+			else if (a.count_bits == 2) hipLaunchKernelGGL((k_column_counts_split<2, false>), grid, dim3(MCHIP_BLOCK), 0, s, a);
+			else if (a.safe_rcp) hipLaunchKernelGGL((k_column_counts_split<4, true>), grid, dim3(MCHIP_BLOCK), 0, s, a);
+			else hipLaunchKernelGGL((k_column_counts_split<4, false>), grid, dim3(MCHIP_BLOCK), 0, s, a);
+			return;
+		}
+	}
 	if (a.sparse && a.count_bits == 2 && a.safe_rcp) { hipLaunchKernelGGL((k_column_counts<2, false, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
 	if (a.sparse && a.count_bits == 4 && a.safe_rcp) { hipLaunchKernelGGL((k_column_counts<4, false, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
 	if (a.sparse && a.count_bits == 2) { hipLaunchKernelGGL((k_column_counts<2, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }

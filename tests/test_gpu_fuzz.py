@@ -91,7 +91,11 @@ def test_random_shapes_mixture_vs_oracle(ctx, I, L, K, ploidy, maxal, missing, s
         np.testing.assert_allclose(ctx.get_q(0), mod.q(0), rtol=1e-7, atol=1e-13)
         np.testing.assert_allclose(ctx.get_p(0), mod.p(0), rtol=1e-7, atol=1e-13)
         np.testing.assert_allclose(ctx.expected_counts(), mod.sik(), rtol=1e-7, atol=1e-12)
-    assert abs(ctx.loglik(0) - mod.loglik(0)) <= max(1e-8, 1e-12 * abs(mod.logL))
+    # the log likelihood of the parameters after the second M step.  Mixture model: v_ik = log eta_k + sum n log p is a sum of
+    # ploidy L terms of size 1-18 (|v| ~ 400 here), rounded differently by the chunked device sums (~1e-12 absolute); exp() turns
+    # that ABSOLUTE error of v into a RELATIVE error of vik, the M step into one of P, and away from a stationary point
+    # d logL ~ |logL| x that: a soak run (MC_FUZZ_SEED=301) found 2.4e-12 |logL| on 65 triploid individuals x 129 loci
+    assert abs(ctx.loglik(0) - mod.loglik(0)) <= max(1e-8, 1e-11 * abs(mod.logL))
 
 
 def draw_cases(n, seed):
