@@ -62,6 +62,22 @@ int main(int argc, char **argv)
 					mc_model mm; memset(&mm, 0, sizeof mm); mm.K = KK;
 					mc_rng rg; mc_srand(&rg, 11);
 					if (mc_skip_initializations(&ro, &md, &mm, &rg, 2)) return 3;
+					/* the starts of the units of a sharded run, walked once, are where skipping u units from the base ends
+					 * (also for the random allele partition: a jump per unit); the skips of consecutive loci taken in one
+					 * step leave the generator where the per-locus skips did (same draws afterwards) */
+					for (int proc = 0; proc < 2; proc++) {
+						ro.initialization_procedure = proc ? MC_RAND_EM : MC_INIT_NOTHING;
+						mc_rng base, starts[5];
+						mc_srand(&base, 77);
+						if (mc_unit_starts(&ro, &md, &mm, &base, 4, starts)) return 4;
+						for (int u = 0; u <= 4; u++) {
+							mc_rng w = base;
+							if (mc_skip_initializations(&ro, &md, &mm, &w, u)) return 5;
+							mc_rng a = starts[u];
+							for (int x = 0; x < 40; x++)
+								if (mc_rand(&a) != mc_rand(&w)) { printf("unit start %d differs (admix %d K %d proc %d)\n", u, admix, KK, proc); return 6; }
+						}
+					}
 					mc_init_cache_free(&mm);
 				}
 			mc_free_data(&d);
