@@ -601,8 +601,12 @@ __global__ __launch_bounds__(QBLOCK, sparse_min_waves(PL, ACCUM)) void k_individ
 		acc[k] = 0.0;
 		if constexpr (DUAL) q2[k] = a.Q2[(size_t)i * a.qstride + k];
 	}
-	if constexpr (SPLIT > 1) {	/* the row slots past K are read by the last lane part: zeros, once (staging writes k < K only) */
-		for (int x = threadIdx.x; x < 2 * a.tile_cols * KP; x += QBLOCK) lds[x] = 0.0;
+	if constexpr (SPLIT > 1 || !NOMISS) {
+		/* once per workgroup: every tile slot holds a finite value from here on.  SPLIT > 1: the row slots past K are read by the
+		 * last lane part (staging writes k < K only).  Missing data: a missing copy borrows column 0 of its locus and multiplies
+		 * it by r = 0; at a locus WITHOUT any allele column (every individual missing: uniquealleles = 0, golden allmiss_*) that
+		 * row is the next locus's, or, behind the tile's last column, whatever the previous kernel left in LDS -- 0 x NaN */
+		for (int x = threadIdx.x; x < (DUAL ? 4 : 2) * a.tile_cols * KP; x += QBLOCK) lds[x] = 0.0;
 		__syncthreads();
 	}
 	const int l0 = blockIdx.y * a.lchunk;

@@ -57,7 +57,7 @@ static char *dup_token(const char *s, size_t len)
 }
 
 /* ---- worker threads ---- */
-enum { RD_OK = 0, RD_SHORT_LINE, RD_NOT_INT, RD_NO_ALLELE, RD_TOO_MANY, RD_NOMEM };
+enum { RD_OK = 0, RD_SHORT_LINE, RD_NOT_INT, RD_TOO_MANY, RD_NOMEM };
 
 typedef struct parse_job {
 	char **cur, **end;		/* per data line: first allele token / end of line */
@@ -138,11 +138,12 @@ static void *locus_main(void *arg)
 		}
 		for (int x = 0; x < nb; x++) {
 			const int l = b0 + x;
-			if (!nu[x]) { j->err = RD_NO_ALLELE; free(uniq); free(nu); return NULL; }
 			if (nu[x] > 254) { j->err = RD_TOO_MANY; free(uniq); free(nu); return NULL; }
-			if (miss[x]) j->missing_data = 1;
-			j->uniquealleles[l] = nu[x] + (miss[x] ? 1 : 0);
-			if (!(j->L_alleles[l] = malloc(sizeof(int) * (size_t)nu[x]))) { j->err = RD_NOMEM; free(uniq); free(nu); return NULL; }
+			/* every haplotype missing at this locus: the reference leaves uniquealleles = 0 and moves on before it would set
+			 * missing_data (read_file.c:524-527): a locus without any allele column (golden allmiss_*) */
+			if (miss[x] && nu[x]) j->missing_data = 1;
+			j->uniquealleles[l] = nu[x] ? nu[x] + (miss[x] ? 1 : 0) : 0;
+			if (!(j->L_alleles[l] = malloc(sizeof(int) * (size_t)(nu[x] ? nu[x] : 1)))) { j->err = RD_NOMEM; free(uniq); free(nu); return NULL; }
 			memcpy(j->L_alleles[l], uniq[x], sizeof(int) * (size_t)nu[x]);
 			if (j->uniquealleles[l] > j->M) j->M = j->uniquealleles[l];
 		}
@@ -333,7 +334,6 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 			if (jobs[t].missing_data) dat->missing_data = 1;
 			if (jobs[t].M > dat->M) dat->M = jobs[t].M;
 		}
-		if (lerr == RD_NO_ALLELE) { FAIL("a locus of '%s' has no observed allele", opt->filename); goto DONE; }
 		if (lerr == RD_TOO_MANY) { FAIL("a locus of '%s' has more than 254 alleles", opt->filename); goto DONE; }
 		if (lerr) { FAIL("out of memory%s", NULL); goto DONE; }
 	}

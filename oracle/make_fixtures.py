@@ -240,7 +240,21 @@ def main():
     miss = os.path.join(data, "missing.stru")
     write_stru(miss, 50, 80, 3, 2, [rnd.choice([2, 2, 3]) for _ in range(80)], seed=3, missing=0.03)
 
+    # loci at which EVERY individual is missing (first of a block of 8, last of one, the file's last locus) beside 3 % scattered
+    # missing copies: the reference gives such a locus uniquealleles = 0, i.e. no allele column at all
+    allmiss = os.path.join(data, "allmiss.stru")
+    write_stru(allmiss, 26, 19, 2, 2, [rnd.choice([2, 3, 4]) for _ in range(19)], seed=12, missing=0.03)
+    rows = open(allmiss).read().strip().split("\n")
+    with open(allmiss, "w") as f:
+        f.write(rows[0] + "\n")
+        for r in rows[1:]:
+            t = r.split()
+            for l in (0, 7, 18):
+                t[2 + l] = "-9"
+            f.write(" ".join(t) + "\n")
     run("c1_admix_k3", c1, 100, "1,2,3,10,100", 5, ["-a", "-k", "3", "-r", "1234567", "-s", "3"], keep_ilm=False)
+    run("allmiss_admix_k2", allmiss, 10, "1,2,3,10", 3, ["-a", "-k", "2", "-r", "3", "-s", "3"])
+    run("allmiss_mix_k2", allmiss, 5, "1,5", 0, ["-k", "2", "-r", "3"])
     run("multi_admix_k4", multi, 30, "1,2,3,10,30", 3, ["-a", "-k", "4", "-r", "7", "-s", "3"])
     run("multi_admix_k4_s1", multi, 3, "1,3", 3, ["-a", "-k", "4", "-r", "7", "-s", "1"])
     run("multi_admix_k4_s2", multi, 3, "1,3", 3, ["-a", "-k", "4", "-r", "7", "-s", "2"])
@@ -316,6 +330,7 @@ def main():
 
     # the reference's own command line: stdout + output files
     run_cli("multi_admix_k4", multi, ["-a", "-k", "4", "-r", "7", "-n", "3"])
+    run_cli("allmiss_admix_k2", allmiss, ["-a", "-k", "2", "-r", "3", "-n", "2"])
     run_cli("missing_admix_k3_s3", miss, ["-a", "-k", "3", "-r", "5", "-n", "2", "-s", "3"])
     run_cli("multi_mix_k3", multi, ["-k", "3", "-r", "5", "-n", "2"])
     run_cli("multi_admix_c_k3", multi, ["-a", "-c", "-k", "3", "-r", "5", "-n", "2"])

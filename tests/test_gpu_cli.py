@@ -63,6 +63,7 @@ def compare_file(ref, got, atol):
     ("missing_admix_k3_noproj", 2e-6),   # --projection: the phantom allele slots of loci with missing data keep p = 0
     ("c1_admix_k3_PQ", 2e-6),            # -P / -Q: initial parameters from files (read_file.c:880-959)
     ("c1_admix_k3_PQ_s3", 5e-3),
+    ("allmiss_admix_k2", 2e-6),          # three loci at which every individual is missing (uniquealleles = 0: no column, no file row)
 ])
 def test_cli_matches_reference_binary(case, atol, tmp_path):
     gdir, out = run_cli(case, tmp_path)
