@@ -252,7 +252,22 @@ def main():
             for l in (0, 7, 18):
                 t[2 + l] = "-9"
             f.write(" ".join(t) + "\n")
+    # monomorphic loci (one allele: p = 1 whatever the cluster), some of them with missing copies (one allele + the phantom slot)
+    mono = os.path.join(data, "mono.stru")
+    write_stru(mono, 21, 26, 3, 2, [rnd.choice([1, 1, 2, 3]) for _ in range(26)], seed=13, missing=0.04)
+    # ploidies the other fixtures do not pin to the reference: haploid, triploid (odd: no pairing of copies), hexaploid (4-bit counts)
+    hap = os.path.join(data, "haploid.stru")
+    write_stru(hap, 33, 30, 2, 1, [rnd.choice([2, 3, 4]) for _ in range(30)], seed=14, missing=0.03)
+    tri = os.path.join(data, "triploid.stru")
+    write_stru(tri, 20, 28, 3, 3, [rnd.choice([2, 3, 4, 5]) for _ in range(28)], seed=15, missing=0.03)
+    hexa = os.path.join(data, "hexaploid.stru")
+    write_stru(hexa, 14, 22, 2, 6, [rnd.choice([2, 3, 4]) for _ in range(22)], seed=16)
     run("c1_admix_k3", c1, 100, "1,2,3,10,100", 5, ["-a", "-k", "3", "-r", "1234567", "-s", "3"], keep_ilm=False)
+    run("mono_admix_k3", mono, 10, "1,2,3,10", 3, ["-a", "-k", "3", "-r", "4", "-s", "3"])
+    run("haploid_admix_k2", hap, 10, "1,2,3,10", 3, ["-p", "1", "-a", "-k", "2", "-r", "4", "-s", "3"])
+    run("triploid_admix_k3", tri, 10, "1,2,3,10", 3, ["-p", "3", "-a", "-k", "3", "-r", "4", "-s", "3"])
+    run("hexaploid_admix_k2", hexa, 10, "1,2,3,10", 3, ["-p", "6", "-a", "-k", "2", "-r", "4", "-s", "3"])
+    run("hexaploid_mix_k2", hexa, 5, "1,5", 0, ["-p", "6", "-k", "2", "-r", "4"])
     run("allmiss_admix_k2", allmiss, 10, "1,2,3,10", 3, ["-a", "-k", "2", "-r", "3", "-s", "3"])
     run("allmiss_mix_k2", allmiss, 5, "1,5", 0, ["-k", "2", "-r", "3"])
     run("multi_admix_k4", multi, 30, "1,2,3,10,30", 3, ["-a", "-k", "4", "-r", "7", "-s", "3"])

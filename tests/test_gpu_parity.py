@@ -16,7 +16,9 @@ from synth import make_dataset, random_params
 pytestmark = pytest.mark.gpu
 
 ADMIX = ["c1_admix_k3", "multi_admix_k4", "tetra_admix_k3", "missing_admix_k3", "multi_admix_k1",
-         "allmiss_admix_k2"]       # loci without any allele column (every individual missing): first / last of a block of 8, last locus
+         "allmiss_admix_k2",       # loci without any allele column (every individual missing): first / last of a block of 8, last locus
+         "mono_admix_k3",          # monomorphic loci, with and without missing copies
+         "haploid_admix_k2", "triploid_admix_k3", "hexaploid_admix_k2"]
 # --projection (unobserved allele columns -- the phantom slot of loci with missing data, alleles with no carrier in a cluster --
 # keep p = 0 for every k) and --bound 1e-120: the reciprocal-per-cell kernel variants (mchip_set_model)
 UNPROJECTED = ["missing_admix_k3_noproj", "multi_admix_k4_noproj", "rare_admix_k3_noproj", "tetra_admix_k3_noproj",
@@ -181,7 +183,7 @@ def test_invalid_inputs_are_rejected(ctx):
 
 # mixlong: 1 800 loci, exp(max_k v_ik) underflows, so the reference's logL_mixture takes its scaling branch
 # (log_likelihood.c:209-224) for ll_after_em
-MIX = ["multi_mix_k3", "missing_mix_k2", "mixlong_mix_k3", "mixslow_mix_k3_s3", "allmiss_mix_k2"]
+MIX = ["multi_mix_k3", "missing_mix_k2", "mixlong_mix_k3", "mixslow_mix_k3_s3", "allmiss_mix_k2", "hexaploid_mix_k2"]
 
 
 @pytest.mark.parametrize("name", MIX)

@@ -52,7 +52,9 @@ def read(path, ploidy=2, missing=-9, r_format=0):
 CASES = [("c1_admix_k3", "c1_tiny.stru", 2, -9), ("multi_admix_k4", "multi.stru", 2, -9),
          ("tetra_admix_k3", "tetra.stru", 4, -9), ("missing_admix_k3", "missing.stru", 2, -9),
          ("reader_interleaved", "multi_interleaved.stru", 2, -9), ("reader_missing99", "missing99.stru", 2, 99),
-         ("allmiss_admix_k2", "allmiss.stru", 2, -9)]       # three loci at which every individual is missing: no allele column at all
+         ("allmiss_admix_k2", "allmiss.stru", 2, -9),
+         ("mono_admix_k3", "mono.stru", 2, -9), ("haploid_admix_k2", "haploid.stru", 1, -9), ("triploid_admix_k3", "triploid.stru", 3, -9),
+         ("hexaploid_admix_k2", "hexaploid.stru", 6, -9)]       # three loci at which every individual is missing: no allele column at all
 
 
 @pytest.mark.parametrize("gold,fn,ploidy,missing", CASES)
