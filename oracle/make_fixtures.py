@@ -262,7 +262,13 @@ def main():
     write_stru(tri, 20, 28, 3, 3, [rnd.choice([2, 3, 4, 5]) for _ in range(28)], seed=15, missing=0.03)
     hexa = os.path.join(data, "hexaploid.stru")
     write_stru(hexa, 14, 22, 2, 6, [rnd.choice([2, 3, 4]) for _ in range(22)], seed=16)
+    # microsatellite-like loci with more than 32 alleles: the device falls back from the sparse individual pass (LDS tiles sized for
+    # <= 32 alleles per locus) to the dense pair of kernels
+    many = os.path.join(data, "manyallele.stru")
+    write_stru(many, 64, 14, 2, 2, [rnd.choice([3, 12, 35, 44]) for _ in range(14)], seed=17, missing=0.02)
     run("c1_admix_k3", c1, 100, "1,2,3,10,100", 5, ["-a", "-k", "3", "-r", "1234567", "-s", "3"], keep_ilm=False)
+    run("manyallele_admix_k2", many, 10, "1,2,3,10", 3, ["-a", "-k", "2", "-r", "4", "-s", "3"])
+    run("missing_admix_c_k2", miss, 10, "1,2,3,10", 3, ["-a", "-c", "-k", "2", "-r", "5", "-s", "3"])
     run("mono_admix_k3", mono, 10, "1,2,3,10", 3, ["-a", "-k", "3", "-r", "4", "-s", "3"])
     run("haploid_admix_k2", hap, 10, "1,2,3,10", 3, ["-p", "1", "-a", "-k", "2", "-r", "4", "-s", "3"])
     run("triploid_admix_k3", tri, 10, "1,2,3,10", 3, ["-p", "3", "-a", "-k", "3", "-r", "4", "-s", "3"])

@@ -25,7 +25,8 @@ def make_fit(g, accel=0, **kw):
 @pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "tetra_admix_k3", "missing_admix_k3",
                                   "multi_admix_k1", "multi_admix_c_k3", "multi_mix_k3", "missing_mix_k2",
                                   "allmiss_admix_k2", "allmiss_mix_k2", "mono_admix_k3", "haploid_admix_k2",
-                                  "triploid_admix_k3", "hexaploid_admix_k2", "hexaploid_mix_k2"])
+                                  "triploid_admix_k3", "hexaploid_admix_k2", "hexaploid_mix_k2",
+                                  "manyallele_admix_k2", "missing_admix_c_k2"])
 def test_em_to_convergence(name):
     g = Golden(name)
     fit = make_fit(g)
@@ -77,7 +78,7 @@ BACKTRACK = ["multi_admix_k4_g3", "multi_admix_k4_s1_g2"]
 @pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "multi_admix_k4_s1", "multi_admix_k4_s2",
                                   "multi_admix_k3_qn1", "tetra_admix_k3", "missing_admix_k3", "multi_admix_c_k3",
                                   "multi_admix_k4_tinybound", "allmiss_admix_k2", "mono_admix_k3", "haploid_admix_k2",
-                                  "triploid_admix_k3", "hexaploid_admix_k2"] + MIX_ACCEL + QN_MULTI + BACKTRACK)
+                                  "triploid_admix_k3", "hexaploid_admix_k2", "manyallele_admix_k2", "missing_admix_c_k2"] + MIX_ACCEL + QN_MULTI + BACKTRACK)
 def test_accelerated_cycles_trace(name):
     """First cycles of SQUAREM / QN with q = 1, 2, 3 secant pairs / SQUAREM with step back-tracking (-g), one after the other from
     the fixture's initial parameters, against the reference's recorded emll, step size, ll, accept, ring index.  With q > 1 the

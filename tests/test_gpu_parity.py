@@ -18,7 +18,9 @@ pytestmark = pytest.mark.gpu
 ADMIX = ["c1_admix_k3", "multi_admix_k4", "tetra_admix_k3", "missing_admix_k3", "multi_admix_k1",
          "allmiss_admix_k2",       # loci without any allele column (every individual missing): first / last of a block of 8, last locus
          "mono_admix_k3",          # monomorphic loci, with and without missing copies
-         "haploid_admix_k2", "triploid_admix_k3", "hexaploid_admix_k2"]
+         "haploid_admix_k2", "triploid_admix_k3", "hexaploid_admix_k2",
+         "manyallele_admix_k2"]    # loci with up to 35 alleles: the dense fallback kernels against the reference itself
+ADMIX_C = ["multi_admix_c_k3", "missing_admix_c_k2"]      # shared mixing proportions (-c), the second on data with missing copies
 # --projection (unobserved allele columns -- the phantom slot of loci with missing data, alleles with no carrier in a cluster --
 # keep p = 0 for every k) and --bound 1e-120: the reciprocal-per-cell kernel variants (mchip_set_model)
 UNPROJECTED = ["missing_admix_k3_noproj", "multi_admix_k4_noproj", "rare_admix_k3_noproj", "tetra_admix_k3_noproj",
@@ -44,7 +46,7 @@ def close(a, b, rtol, atol):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize("name", ADMIX + ["multi_admix_c_k3"])
+@pytest.mark.parametrize("name", ADMIX + ADMIX_C)
 def test_param_roundtrip(ctx, name):
     g = Golden(name)
     setup_case(ctx, g)
@@ -52,7 +54,7 @@ def test_param_roundtrip(ctx, name):
     assert np.array_equal(ctx.get_q(0), g.q("q0"))
 
 
-@pytest.mark.parametrize("name", ADMIX + ["multi_admix_c_k3"] + UNPROJECTED)
+@pytest.mark.parametrize("name", ADMIX + ADMIX_C + UNPROJECTED)
 def test_em_steps_vs_reference_golden(ctx, name):
     g = Golden(name)
     setup_case(ctx, g)

@@ -54,7 +54,7 @@ CASES = [("c1_admix_k3", "c1_tiny.stru", 2, -9), ("multi_admix_k4", "multi.stru"
          ("reader_interleaved", "multi_interleaved.stru", 2, -9), ("reader_missing99", "missing99.stru", 2, 99),
          ("allmiss_admix_k2", "allmiss.stru", 2, -9),
          ("mono_admix_k3", "mono.stru", 2, -9), ("haploid_admix_k2", "haploid.stru", 1, -9), ("triploid_admix_k3", "triploid.stru", 3, -9),
-         ("hexaploid_admix_k2", "hexaploid.stru", 6, -9)]       # three loci at which every individual is missing: no allele column at all
+         ("hexaploid_admix_k2", "hexaploid.stru", 6, -9), ("manyallele_admix_k2", "manyallele.stru", 2, -9)]       # three loci at which every individual is missing: no allele column at all
 
 
 @pytest.mark.parametrize("gold,fn,ploidy,missing", CASES)
