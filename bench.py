@@ -25,9 +25,13 @@ Workloads
 
 value = EM iterations/s summed over ranks (n_iter increments of stop(), em_alg.c:103, over the barrier-to-barrier wall time,
 max over ranks), inputs resident in HBM.  The same JSON line carries `roofline` for the dominant kernel (HIP events on the
-library's own stream) and, at N = 1, `cpu_baseline` (the CPU oracle on a bounded sample, rank 0; one host core for the single
-fits, min(units, 16) processes at once -- one unit each -- for c4 and c5; the oracle is only the baseline and the checker here,
-never the measured path) with `parity` = the HIP path on that same sample against it.
+library's own stream) and, at N = 1, `cpu_baseline`: rank 0 times the reference's own em() (oracle/_ref/ref_time: the
+unmodified sources of the path compiled by oracle/Makefile where /root/reference exists; the binary travels with the tree,
+the sources do not; kind "reference") on a bounded sample of the workload -- all individuals, the first loci, the same
+iterations -- and, under `port`, the CPU oracle on a larger one (one host core for the single fits, min(units, 16) processes
+at once -- one unit each -- for c4 and c5).  Both carry `parity` = the HIP path on their own sample against them.  Without the
+binary the object leads with the oracle (kind "port").  Reference and oracle are the baseline and the checker here, never the
+measured path.
 """
 import argparse
 import ctypes as C
@@ -262,7 +266,7 @@ def cpu_worker(path):
     print(json.dumps({"iters": int(mod.n_iter), "dt": dt}), flush=True)
 
 
-def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0, units=1):
+def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0, units=1, ref_budget_s=15.0):
     """The CPU oracle (oracle/mc_oracle.c, fused order) on a bounded sample of the same workload: the first L_s loci of every
     individual, sized for about `budget_s` seconds of one host core.  A workload of independent units (c4's initialisations,
     c5's replicates: SURVEY.md 8d, the reference's own scaling model) is timed on min(units, host cores) processes at once,
@@ -338,14 +342,105 @@ def cpu_baseline(w, ua, geno, accel, budget_s=20.0, device=0, units=1):
         "value": 1.0 / (ref_ns_per_cell * 1e-9 * ref_cells), "unit": "EM iterations/s", "cores": 1, "kind": "extrapolation",
         "basis": "BASELINE.md section 2: %.0f ns per (i,l,m,k) cell measured for the unmodified reference on one 2.1 GHz Xeon core at "
                  "config-1 and config-2 size, times I*T*K = %.3g cells; the reference cannot run this size (diklm alone is 0.5 TB at "
-                 "config 3), and its sources do not travel to the GPU box" % (ref_ns_per_cell, ref_cells),
+                 "config 3)" % (ref_ns_per_cell, ref_cells),
     }
-    return {
-        "reference_extrapolated": reference_extrapolated,
+    port = {
         "value": sum(rates) * Ls / L, "unit": "EM iterations/s", "cores": procs, "kind": "port",
         "sample": "first %d of %d loci, all %d individuals, %d EM iterations (%s) in %.1f s %s; "
                   "scaled by %d/%d (cost is linear in loci)" % (Ls, L, I, mod.n_iter, "SQUAREM-3 cycles" if accel else "plain EM", dt, how, Ls, L),
         "sample_value": sum(rates), "parity": parity,
+    }
+    ref = reference_leg(w, ua_s, geno_s, q0, p0, accel, iters, procs, ref_budget_s, device, int(ua.sum()))
+    if ref is None:
+        port["reference_extrapolated"] = reference_extrapolated
+        port["reference"] = "oracle/_ref/ref_time is not in this tree (it is built where /root/reference exists): the CPU figure is the oracle's"
+        return port
+    ref["port"] = port
+    ref["reference_extrapolated"] = reference_extrapolated
+    return ref
+
+
+def gpu_over_cpu(out):
+    """the ratio against the baseline the object leads with (the reference itself where its binary is in the tree) and,
+    then, against the oracle too"""
+    cb = out["cpu_baseline"]
+    cb["gpu_over_cpu"] = out["value"] / cb["value"]
+    if "port" in cb:
+        cb["port"]["gpu_over_cpu"] = out["value"] / cb["port"]["value"]
+
+
+REF_TIME = os.path.join(ROOT, "oracle", "_ref", "ref_time")
+
+
+def reference_leg(w, ua_s, geno_s, q0, p0, accel, iters, procs, budget_s, device, T_full):
+    """The reference's own em() (oracle/ref_time.c: the unmodified sources of the path, compiled in place by oracle/Makefile;
+    the binary travels, the sources do not) on the head of the oracle's sample, sized for about `budget_s` seconds of one host
+    core: all individuals, the first L_r loci, `iters` EM iterations from the same starting parameters -- and the same
+    iterations through the HIP path, compared with what the reference left.  None where the binary is absent."""
+    if not os.access(REF_TIME, os.X_OK) or budget_s <= 0:
+        return None
+    import tempfile
+    I, p, K = w["I"], w["ploidy"], w["K"]
+    cum = np.cumsum(ua_s)
+    args = ["-f", "sample", "-a", "-k", str(K)] + (["-s", str(accel)] if accel else [])
+
+    def run(seconds, ns_per_cell):
+        cols = max(1, int(seconds * 1e9 / (ns_per_cell * I * K * iters)))
+        Lr = int(max(1, min(len(ua_s), np.searchsorted(cum, cols, side="right"))))
+        Tr = int(cum[Lr - 1])
+        ua_r, geno_r = np.ascontiguousarray(ua_s[:Lr], dtype=np.int32), np.ascontiguousarray(geno_s[:, :Lr, :])
+        p0_r = np.ascontiguousarray(p0[:, :Tr])
+        with tempfile.TemporaryDirectory(prefix="mcref.") as d:
+            ua_r.tofile(os.path.join(d, "ua.i32"))
+            geno_r.tofile(os.path.join(d, "geno.u8"))
+            np.ascontiguousarray(q0).tofile(os.path.join(d, "q0.f64"))
+            p0_r.tofile(os.path.join(d, "p0.f64"))
+            cmd = [REF_TIME, d, str(I), str(Lr), str(p), str(K), str(iters - 1), "--"] + args
+            # independent units (c4, c5): the reference's scaling model is one process per unit (multiclust.c:143-145)
+            runs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(procs)]
+            outs = [r.communicate() for r in runs]
+            if any(r.returncode for r in runs):
+                raise SystemExit("cpu_baseline: the reference run failed: %s" % outs[0][1][-400:])
+            res = [json.loads(o[0]) for o in outs]
+            q_ref = np.fromfile(os.path.join(d, "q_ref.f64")).reshape(I, K)
+            p_ref = np.fromfile(os.path.join(d, "p_ref.f64")).reshape(K, Tr)
+        return Lr, Tr, ua_r, geno_r, p0_r, res, q_ref, p_ref
+
+    # its cost per (individual, allele column, cluster) cell and counted iteration depends on the host and on I (the jagged
+    # diklm rows miss the caches more as I grows): 9 ns on a GPU box's host, 30-65 ns on the build container.  A pilot a
+    # tenth of the budget at the slow figure, then the sample the budget allows at the measured one
+    Lr, Tr, ua_r, geno_r, p0_r, res, q_ref, p_ref = run(budget_s / 10.0, 60.0)
+    pilot_ns = 1e9 * max(r["em_s"] for r in res) / res[0]["n_iter"] / (float(I) * Tr * K)
+    if Lr < len(ua_s) and pilot_ns < 50.0:
+        Lr, Tr, ua_r, geno_r, p0_r, res, q_ref, p_ref = run(0.85 * budget_s, max(pilot_ns, 1.0))
+    r0 = res[0]
+    rates = [r["n_iter"] / r["em_s"] for r in res]
+    from multiclust_amd import host
+    fit = host.Fit(ua_r, geno_r, K, device=device, admixture=1, accel_scheme=accel, verbosity=1, abs_error=1e-300, rel_error=0.0,
+                   max_iter=iters - 1)
+    fit.set_params(q0, p0_r)
+    fit.em()
+    gq, gp = fit.get_q(fit.mod.pindex), fit.get_p(fit.mod.pindex)
+    big_q, big_p = q_ref > 1e-6, p_ref > 1e-6
+    parity = {
+        "abs_dlogL": abs(fit.mod.logL - r0["logL"]), "rel_dlogL": abs(fit.mod.logL - r0["logL"]) / abs(r0["logL"]),
+        "max_rel_dQ": float(np.max(np.abs(gq - q_ref)[big_q] / q_ref[big_q])),
+        "max_rel_dP": float(np.max(np.abs(gp - p_ref)[big_p] / p_ref[big_p])),
+        "same_n_iter": int(fit.mod.n_iter == r0["n_iter"]),
+        "note": "HIP path (mc_em) vs the reference's em() on this sample: same starting parameters, same stopping rule "
+                "(-T %d); Q/P entries > 1e-6" % (iters - 1),
+    }
+    fit.close()
+    how = "on one core" if procs == 1 else "on each of %d processes at once (one unit each; rates summed: %.4f-%.4f it/s per process)" % (
+        procs, min(rates), max(rates))
+    return {
+        "value": sum(rates) * Tr / T_full, "unit": "EM iterations/s", "cores": procs, "kind": "reference",
+        "sample": "the reference's em() (unmodified sources, gcc -O3, its reader bypassed: oracle/ref_time.c) on the first %d of %d "
+                  "loci (%d of %d allele columns), all %d individuals, %d EM iterations (%s) in %.1f s %s, %.1f s of allocation "
+                  "before them; scaled by %d/%d (cost is linear in allele columns)" % (
+                      Lr, w["L"], Tr, T_full, I, r0["n_iter"], "SQUAREM-%d cycles" % accel if accel else "plain EM", r0["em_s"], how,
+                      r0["setup_s"], Tr, T_full),
+        "sample_value": sum(rates), "ns_per_cell": 1e9 * r0["em_s"] / r0["n_iter"] / (float(I) * Tr * K), "parity": parity,
     }
 
 
@@ -721,7 +816,9 @@ def main():
     ap.add_argument("--stability", type=int, default=5, help="single-fit workloads: repeat the timed batch this many times behind the "
                     "timed region and report min / median / max EM iterations/s (0: off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of one host core for the CPU oracle's sample")
+    ap.add_argument("--ref-budget", type=float, default=15.0, help="seconds of one host core for the reference's own em() on the "
+                    "head of that sample (oracle/_ref/ref_time; 0: skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra workloads carried on the default line (profiling "
                     "runs: their kernels have the same names as the headline workload's)")
     args = ap.parse_args()
@@ -740,8 +837,8 @@ def main():
         ua, geno = workload_data(w, env)
         out = run_bootstrap(env, w, ua, geno, args.replicates, args.steps, n_streams=args.streams)
         if want_cpu:
-            out["cpu_baseline"] = cpu_baseline(w, ua, geno, 0, args.cpu_budget, env.local_rank, units=args.replicates)
-            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline"] = cpu_baseline(w, ua, geno, 0, args.cpu_budget, env.local_rank, units=args.replicates, ref_budget_s=args.ref_budget)
+            gpu_over_cpu(out)
         if env.rank == 0:
             finish(env, args, out, "strong")
         env.close()
@@ -756,8 +853,8 @@ def main():
         out = run_units(env, fit, w, T, args.units, args.steps, args.warmup)
         fit.close()
         if want_cpu:
-            out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget, env.local_rank, units=args.units)
-            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget, env.local_rank, units=args.units, ref_budget_s=args.ref_budget)
+            gpu_over_cpu(out)
         if env.rank == 0:
             finish(env, args, out, "strong")
         env.close()
@@ -765,8 +862,8 @@ def main():
 
     out, fit, accel = run_single_fit(args, env, name, ua, geno, args.steps, args.warmup)
     if want_cpu:
-        out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget, env.local_rank)
-        out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        out["cpu_baseline"] = cpu_baseline(w, ua, geno, accel, args.cpu_budget, env.local_rank, ref_budget_s=args.ref_budget)
+        gpu_over_cpu(out)
     # the other BASELINE.json configurations on the same line (plain numbers, same measurement rules): configs[1] (c2) at
     # N = 1; configs[3] (c4: 50 initialisations sharded) at every N; configs[4] (c5: 200 bootstrap replicates sharded) at N > 1
     if name == "c3" and not args.no_secondary:

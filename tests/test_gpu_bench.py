@@ -129,3 +129,27 @@ def test_ranks_with_different_data_sets_stop_before_the_timed_region():
                     {"MC_BENCH_DEVICE": "0", "MC_BENCH_BACKEND": "gloo", "MC_BENCH_CORRUPT_RANK": "1"}, expect_failure=True)
     assert res.returncode != 0 and '{"metric"' not in res.stdout
     assert "the synthetic data set differs between ranks" in res.stderr
+
+
+@pytest.mark.parametrize("workload,extra", [("c1", []), ("c4s", ["--units", "3"]), ("c5s", ["--replicates", "3"])])
+def test_cpu_baseline_legs_on_small_workloads(workload, extra):
+    """`cpu_baseline` leads with the reference's own em() (oracle/_ref/ref_time, kind "reference") where that binary is in the
+    tree, the oracle ("port") under it; both carry the HIP path's distance from them on their own sample, inside BASELINE.json's
+    tolerances."""
+    out = run_bench(["--workload", workload, "--steps", "4", "--warmup", "1", "--settle", "0", "--stability", "0", "--no-secondary",
+                     "--cpu-budget", "0.5", "--ref-budget", "0.5"] + extra, {})
+    cb = out["cpu_baseline"]
+    have_ref = os.access(os.path.join(ROOT, "oracle", "_ref", "ref_time"), os.X_OK)
+    assert cb["kind"] == ("reference" if have_ref else "port")
+    port = cb["port"] if have_ref else cb
+    for leg in ([cb, port] if have_ref else [port]):
+        assert leg["unit"] == "EM iterations/s" and leg["value"] > 0 and leg["cores"] >= 1 and leg["sample"]
+        par = leg["parity"]
+        # logL: 1e-8 absolute at config-1 scale; beyond it 1e-12 relative (BASELINE.md section 3.5: the reference's own running sum
+        # is no better than that at |logL| ~ 1e6)
+        assert par["same_n_iter"] == 1 and (par["abs_dlogL"] <= 1e-8 or par["rel_dlogL"] <= 1e-12), par
+        assert par["max_rel_dQ"] <= 1e-6 and par["max_rel_dP"] <= 1e-6, par
+        assert abs(leg["gpu_over_cpu"] * leg["value"] - out["value"]) <= 1e-9 * out["value"]
+    assert cb["reference_extrapolated"]["kind"] == "extrapolation"
+    if have_ref:
+        assert 1 < cb["ns_per_cell"] < 500 and cb["value"] < port["value"]     # the oracle restates it without diklm: faster

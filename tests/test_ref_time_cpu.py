@@ -1,0 +1,55 @@
+"""oracle/_ref/ref_time (the reference's own em() on flat arrays: bench.py's `cpu_baseline` kind "reference") against the CPU
+oracle in reference operation order: the same iterate, bit for bit.  The reader bypass of oracle/ref_time.c therefore hands the
+reference the data it would have read.  Skipped where the binary is absent (it is built where /root/reference exists)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+from golden_util import Golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_TIME = os.path.join(ROOT, "oracle", "_ref", "ref_time")
+pytestmark = pytest.mark.skipif(not os.access(REF_TIME, os.X_OK), reason="oracle/_ref/ref_time not built")
+
+
+@pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "tetra_admix_k3", "hexaploid_admix_k2"])
+@pytest.mark.parametrize("accel,max_iter", [(0, 5), (3, 7), (1, 9)])
+def test_reference_em_on_flat_arrays_equals_the_oracle(tmp_path, name, accel, max_iter):
+    g = Golden(name)
+    I, L, p = g.geno.shape
+    d = str(tmp_path)
+    g.ua.astype(np.int32).tofile(d + "/ua.i32")
+    g.geno.tofile(d + "/geno.u8")
+    q0, p0 = g.q("q0"), g.p("p0")
+    q0.tofile(d + "/q0.f64")
+    p0.tofile(d + "/p0.f64")
+    cmd = [REF_TIME, d, str(I), str(L), str(p), str(g.K), str(max_iter), "--", "-f", "x", "-a", "-k", str(g.K)]
+    res = subprocess.run(cmd + (["-s", str(accel)] if accel else []), capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    j = json.loads(res.stdout)
+    opt = ob.make_options(lower_bound=j["lower_bound"], fused=0, accel_scheme=accel, abs_error=1e-300, max_iter=max_iter)
+    mod = ob.Model(ob.Data(I, L, p, g.ua, g.geno), opt, g.K)
+    mod.q(0)[...] = q0
+    mod.p(0)[...] = p0
+    mod.em()
+    assert j["n_iter"] == mod.n_iter == max_iter + 1 and j["iter_stop"] == 1
+    assert j["logL"] == mod.logL
+    assert np.array_equal(np.fromfile(d + "/q_ref.f64").reshape(I, g.K), mod.q(mod.pindex))
+    assert np.array_equal(np.fromfile(d + "/p_ref.f64").reshape(g.K, -1), mod.p(mod.pindex))
+
+
+def test_missing_data_is_refused(tmp_path):
+    g = Golden("missing_admix_k3")
+    I, L, p = g.geno.shape
+    d = str(tmp_path)
+    g.ua.astype(np.int32).tofile(d + "/ua.i32")
+    g.geno.tofile(d + "/geno.u8")
+    g.q("q0").tofile(d + "/q0.f64")
+    g.p("p0").tofile(d + "/p0.f64")
+    res = subprocess.run([REF_TIME, d, str(I), str(L), str(p), str(g.K), "3", "--", "-f", "x", "-a", "-k", str(g.K)],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 2 and "missing data is not supported" in res.stderr
