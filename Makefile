@@ -51,7 +51,7 @@ oracle: $(LIB)/libmulticlust_host.so
 	$(MAKE) -C oracle all
 
 # microbenchmarks behind profiles/r01_fp64_microbench.txt and r01_op_cost_microbench.txt (run on the GPU box; binaries are not tracked)
-micro: scripts/micro/fp64_micro scripts/micro/op_cost scripts/micro/lds_valu scripts/micro/vgpr_banks
+micro: scripts/micro/fp64_micro scripts/micro/op_cost scripts/micro/lds_valu scripts/micro/vgpr_banks scripts/micro/mfma_sustained
 scripts/micro/%: scripts/micro/%.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 
@@ -93,7 +93,7 @@ exp-k: $(LIB)/libmulticlust_hip.so
 		$(filter-out $(OBJ)/mchip_k$(EXPK).o,$(OBJ)/mchip.o $(OBJ)/mchip_comm.o $(KOBJ)) build/exp/mchip_k$(EXPK)_$(EXPNAME).o -ldl
 
 clean:
-	rm -rf build $(LIB)/*.so $(BIN) scripts/micro/fp64_micro scripts/micro/op_cost scripts/micro/lds_valu scripts/micro/vgpr_banks scripts/exp/*.so
+	rm -rf build $(LIB)/*.so $(BIN) scripts/micro/fp64_micro scripts/micro/op_cost scripts/micro/lds_valu scripts/micro/vgpr_banks scripts/micro/mfma_sustained scripts/exp/*.so
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle micro exp-scatter exp-k52 exp-k8 exp-k clean

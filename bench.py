@@ -451,8 +451,9 @@ PASS_KERNELS = {"column_pass": ("k_column_counts", "k_column_counts (N-side sums
                 "loglik_pass": ("k_individual_sparse<2, false", "k_individual_sparse (stand-alone log likelihood)"),
                 "individual_dual_pass": ("k_individual_sparse<2, true, false, true, true>",
                                          "k_individual_sparse, dual (S-side sums of the extrapolated point + logL of the second EM iterate)")}
-FP64_SUSTAINED_TF = 57.9     # v_fma_f64 stream with its in-kernel clock stamped: 1.79-1.92 GHz under FP64 load, 4.3-4.4 cycles per
-                             # wave-instruction (profiles/r03_lds_valu_microbench.txt); the spec peak assumes 2.4 GHz and 4.0
+FP64_SUSTAINED_TF = 62.0     # v_fma_f64 stream on operands that keep changing, held for 5 s: 2.00-2.05 GHz (power management; 2.35 GHz
+                             # and 71-74 TF/s on constant operands), 4.3-4.4 cycles per wave-instruction
+                             # (profiles/r03_fp64_sustained_clock.txt); the spec peak assumes 2.4 GHz and 4.0
 
 
 def latest_traffic(tag):
@@ -507,9 +508,9 @@ def build_roofline(w, T, K, kernel_ms, launches, steps, it_per_s_per_gpu, nnz, t
                       "reachable at FP64 (about 45 flop per genotype byte at K = 8 against a ridge of 10).  fp64_valu_frac = "
                       "(5K+5) flop per NON-EMPTY cell (SURVEY.md 8d; cells counted on the device at upload) x iterations/s over "
                       "the 78.6 TF/s vector-FP64 spec peak; _dense_cells counts every (individual, allele column) cell, which is "
-                      "what the column pass multiplies through; _of_sustained is the same over the %.1f TF/s a pure v_fma_f64 "
-                      "stream sustains on this chip (the clock drops to 1.8-1.9 GHz under FP64 load: "
-                      "profiles/r03_lds_valu_microbench.txt)" % FP64_SUSTAINED_TF,
+                      "what the column pass multiplies through; _of_sustained is the same over the %.1f TF/s a v_fma_f64 stream on "
+                      "changing operands sustains on this chip (power management holds it at 2.0-2.05 GHz; the EM passes run at "
+                      "2.02-2.14 GHz: profiles/r03_fp64_sustained_clock.txt)" % FP64_SUSTAINED_TF,
     }
 
 
