@@ -583,7 +583,9 @@ def run_single_fit(args, env, name, ua, geno, steps, warmup, with_roofline=True)
         else:
             rc = hlib.mchip_em_run(ctx, 0, n, C.byref(st))
         if rc or st.fatal or st.stopped:
-            raise SystemExit("batched run: rc=%d fatal=%d stopped=%d" % (rc, st.fatal, st.stopped))
+            raise SystemExit("batched run: rc=%d fatal=%d stopped=%d after %d iterations%s" % (
+                rc, st.fatal, st.stopped, st.n_iter, " (the fit reached its fixed point to the last bit inside the timed region: use fewer "
+                "--steps for a workload this small)" if st.stopped and not (rc or st.fatal) else ""))
         fit.mod.n_iter, fit.mod.logL = st.n_iter, st.logL
 
     env.barrier(ctx)

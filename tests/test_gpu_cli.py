@@ -22,7 +22,9 @@ def run_cli(case, tmp_path, extra=()):
     args = open(os.path.join(gdir, "ARGS.txt")).read().split()
     stru = os.path.join(GOLD, "data", args[1])
     rest = [os.path.join(GOLD, "data", a) if os.path.exists(os.path.join(GOLD, "data", a)) else a for a in args[2:]]   # -P / -Q files
-    cmd = [BIN, "-f", stru, "-d", str(tmp_path)] + rest + list(extra)
+    # -d with its trailing slash: the reference's own mixture writers size their file-name buffers without the separator they
+    # insert when it is missing (write_file.c:628-640,707-711), one byte short; tests/test_gpu_refbind.py runs that code
+    cmd = [BIN, "-f", stru, "-d", os.path.join(str(tmp_path), "")] + rest + list(extra)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
     run_cli.last_stderr = res.stderr
