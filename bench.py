@@ -606,6 +606,8 @@ def run_single_fit(args, env, name, ua, geno, steps, warmup, with_roofline=True)
                    "accel_scheme": accel, "em_iterations_per_step": 2 if accel else 1,
                    "units": "%d initialisation(s), one per GPU" % env.world, "best_logL": best},
     }
+    if accel:      # with an accelerated scheme both rates; a cycle = 2 EM iterations + 2 log-likelihood evaluations
+        out["config"]["accelerated_cycles_per_s"] = steps * env.world / dt
     if with_roofline and env.rank == 0:
         nnz, _ = data_counts(ctx)
         out["roofline"] = roofline_object(ctx, w, T, w["K"], value / env.world, name, nnz, steps)
