@@ -3,8 +3,8 @@ own sources compiled by oracle/Makefile in the build container; the binary trave
 multiclust_amd/bin/multiclust run the same freshly generated STRUCTURE files with the same arguments; stdout lines (iteration
 counts exactly for plain EM) and the five output files must agree as in tests/test_gpu_cli.py.  Where test_gpu_cli.py compares
 with committed outputs of twelve command lines, this draws its cases: ploidy 1-4, K 2-6, admixture / -c / mixture, every
-acceleration scheme, -n 2 (two initialisations from one rand() stream), -i, -T, --projection, --bound, -E / -e.  No missing values: with them the reference's
-reader leaves an allele slot uninitialised and its results depend on the length of its path strings (oracle/make_fixtures.py).
+acceleration scheme, -n 2 (two initialisations from one rand() stream), -i, -T, --projection, --bound, -E / -e, and 3 % missing
+values in a quarter of the cases (a case is skipped when the reference's uninitialised allele slot spoils ITS run).
 Skipped where the reference binary is absent."""
 import os
 import random
@@ -45,7 +45,7 @@ def draw_cases(n, seed):
             # stopped 0.1-0.5 log-likelihood units apart from the reference, 2-30 iterations earlier or later): the first 40
             # iterations are compared here, every cycle of whole reference runs in test_gpu_host_driver.py
             extra = (extra + " -T 40").strip()
-        out.append((c, I, L, ploidy, K, model, scheme, extra, rnd.randrange(1, 10 ** 6)))
+        out.append((c, I, L, ploidy, K, model, scheme, extra, rnd.randrange(1, 10 ** 6) * 10 + rnd.choice([0, 0, 0, 3])))
     return out
 
 
@@ -54,10 +54,12 @@ def draw_cases(n, seed):
 @pytest.mark.parametrize("c,I,L,ploidy,K,model,scheme,extra,seed",
                          draw_cases(int(os.environ.get("MC_DIFF_CASES", "24")), 20250117 + int(os.environ.get("MC_DIFF_SEED", "0"))))
 def test_command_line_against_the_reference_program_on_drawn_cases(c, I, L, ploidy, K, model, scheme, extra, seed, tmp_path):
-    from make_fixtures import write_stru
+    from make_fixtures import write_stru, phantom_slots
+    seed, missing = seed // 10, (seed % 10) / 100.0        # 0 or 3 % of the allele copies missing
     rnd = random.Random(seed)
     stru = str(tmp_path / ("d%d.stru" % c))
-    write_stru(stru, I, L, max(2, K - 1), ploidy, [rnd.choice([2, 2, 3, 4, 5]) for _ in range(L)], seed=seed)
+    write_stru(stru, I, L, max(2, K - 1), ploidy, [rnd.choice([2, 2, 3, 4, 5]) for _ in range(L)], seed=seed, missing=missing)
+    phantom = phantom_slots(stru, ploidy) if missing else {}
     args = ["-p", str(ploidy), "-k", str(K), "-r", str(seed % 9973 + 1)] + model.split() + extra.split()
     if "-n" not in args:
         args += ["-n", "1"]
@@ -71,6 +73,19 @@ def test_command_line_against_the_reference_program_on_drawn_cases(c, I, L, ploi
                              text=True, timeout=300, cwd=str(d))
         open(str(tmp_path / (name + ".stdout")), "w").write(res.stdout)        # kept for scripts/diag/diffcase.sh
         open(str(tmp_path / (name + ".stderr")), "w").write(" ".join(args) + "\n" + res.stderr)
+        if name == "ref" and phantom:
+            # Missing values: the reference's reader counts an allele slot for the missing code and never initialises it
+            # (read_file.c:527-533 against 581-585).  When the heap garbage in it equals an allele code the reference fits another
+            # model, and depending on the length of its path strings it aborts in free(): such a run is no reference for anything
+            # (oracle/make_fixtures.py keeps the same rule for the committed goldens)
+            if res.returncode != 0:
+                pytest.skip("the reference aborted (uninitialised allele slot): %s" % res.stderr.strip()[-80:])
+            for fn in os.listdir(str(d)):
+                if fn.endswith("pklm.txt"):
+                    for row in open(os.path.join(str(d), fn)).read().strip().split("\n")[1:]:
+                        k_, l_, m_, v_ = row.split()
+                        if phantom.get(int(l_)) == int(m_) and v_ != "0.000000":
+                            pytest.skip("heap garbage in the reference's phantom allele slot matched an allele code")
         assert res.returncode == 0, (name, args, res.stderr[-2000:])
         outs[name] = (cli.CLOCK.sub("HH:MM:SS", res.stdout).strip().split("\n"), d)
     (ref_lines, ref_dir), (got_lines, got_dir) = outs["ref"], outs["hip"]
