@@ -13,8 +13,8 @@
  * the HIP path gets, and the starting parameters are written into slot 0 (where initialize_model() leaves its own).  No
  * missing data in the sample (the synthetic bench workloads have none), so no phantom allele slots.
  *
- * usage: ref_time <dir> <I> <L> <ploidy> <K> <max_iter> -- <multiclust argv: -f x -a -k K [-s n]>
- *   <dir>/ua.i32 [L], geno.u8 [I][L][ploidy] (allele index), q0.f64 [I][K], p0.f64 [K][T]
+ * usage: ref_time <dir> <I> <L> <ploidy> <K> <max_iter> -- <multiclust argv: -f x [-a [-c]] -k K [-s n]>
+ *   <dir>/ua.i32 [L], geno.u8 [I][L][ploidy] (allele index), q0.f64 [I][K] ([K] with -c and for the mixture model), p0.f64 [K][T]
  * writes <dir>/q_ref.f64, p_ref.f64 (final iterate) and prints one JSON line.
  */
 #define _POSIX_C_SOURCE 200809L
@@ -116,10 +116,15 @@ int main(int argc, const char **argv)
 	if (allocate_model_for_k(opt, mod, dat)) die("allocate_model_for_k failed");
 	double t_alloc = now() - t0;
 
-	double *q0 = slurp(dir, "q0.f64", (size_t)I * K * sizeof(double));
+	/* mixing proportions: one row per individual, or one row in all with -c and for the mixture model (multiclust.c:1199-1226) */
+	const int shared_eta = !opt->admixture || opt->eta_constrained;
+	double *q0 = slurp(dir, "q0.f64", (shared_eta ? (size_t)K : (size_t)I * K) * sizeof(double));
 	double *p0 = slurp(dir, "p0.f64", (size_t)K * T * sizeof(double));
-	for (int i = 0; i < I; i++)
-		for (int k = 0; k < K; k++) mod->vetaik[0][i][k] = q0[(size_t)i * K + k];
+	if (shared_eta)
+		for (int k = 0; k < K; k++) mod->vetak[0][k] = q0[k];
+	else
+		for (int i = 0; i < I; i++)
+			for (int k = 0; k < K; k++) mod->vetaik[0][i][k] = q0[(size_t)i * K + k];
 	for (int k = 0; k < K; k++) {
 		size_t t = 0;
 		for (int l = 0; l < L; t += ua[l], l++)
@@ -142,7 +147,8 @@ int main(int argc, const char **argv)
 	snprintf(path, sizeof path, "%s/q_ref.f64", dir);
 	FILE *f = fopen(path, "wb");
 	if (!f) die("cannot write q_ref.f64");
-	for (int i = 0; i < I; i++) fwrite(mod->vetaik[mod->pindex][i], sizeof(double), K, f);
+	if (shared_eta) fwrite(mod->vetak[mod->pindex], sizeof(double), K, f);
+	else for (int i = 0; i < I; i++) fwrite(mod->vetaik[mod->pindex][i], sizeof(double), K, f);
 	fclose(f);
 	snprintf(path, sizeof path, "%s/p_ref.f64", dir);
 	f = fopen(path, "wb");

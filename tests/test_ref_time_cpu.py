@@ -16,10 +16,15 @@ REF_TIME = os.path.join(ROOT, "oracle", "_ref", "ref_time")
 pytestmark = pytest.mark.skipif(not os.access(REF_TIME, os.X_OK), reason="oracle/_ref/ref_time not built")
 
 
-@pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "tetra_admix_k3", "hexaploid_admix_k2"])
+@pytest.mark.parametrize("name", ["c1_admix_k3", "multi_admix_k4", "tetra_admix_k3", "hexaploid_admix_k2",
+                                  "multi_admix_c_k3", "multi_mix_k3", "hexaploid_mix_k2"])        # -c and the mixture model: one row of eta
 @pytest.mark.parametrize("accel,max_iter", [(0, 5), (3, 7), (1, 9)])
 def test_reference_em_on_flat_arrays_equals_the_oracle(tmp_path, name, accel, max_iter):
     g = Golden(name)
+    if g.m["eta_constrained"] or not g.m["admixture"]:
+        # one row of eta: the fit is at its fixed point to the last bit within a few iterations, and with "never converged"
+        # (abs_error 1e-300) the next accelerated cycle ends in the reference's exit on a log likelihood lower by one ulp
+        max_iter = min(max_iter, 3)
     I, L, p = g.geno.shape
     d = str(tmp_path)
     g.ua.astype(np.int32).tofile(d + "/ua.i32")
@@ -27,18 +32,21 @@ def test_reference_em_on_flat_arrays_equals_the_oracle(tmp_path, name, accel, ma
     q0, p0 = g.q("q0"), g.p("p0")
     q0.tofile(d + "/q0.f64")
     p0.tofile(d + "/p0.f64")
-    cmd = [REF_TIME, d, str(I), str(L), str(p), str(g.K), str(max_iter), "--", "-f", "x", "-a", "-k", str(g.K)]
+    model = (["-a"] if g.m["admixture"] else []) + (["-c"] if g.m["eta_constrained"] else [])
+    cmd = [REF_TIME, d, str(I), str(L), str(p), str(g.K), str(max_iter), "--", "-f", "x"] + model + ["-k", str(g.K)]
     res = subprocess.run(cmd + (["-s", str(accel)] if accel else []), capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
     j = json.loads(res.stdout)
-    opt = ob.make_options(lower_bound=j["lower_bound"], fused=0, accel_scheme=accel, abs_error=1e-300, max_iter=max_iter)
+    opt = ob.make_options(admixture=g.m["admixture"], eta_constrained=g.m["eta_constrained"], lower_bound=j["lower_bound"], fused=0,
+                          accel_scheme=accel, abs_error=1e-300, max_iter=max_iter)
     mod = ob.Model(ob.Data(I, L, p, g.ua, g.geno), opt, g.K)
     mod.q(0)[...] = q0
     mod.p(0)[...] = p0
     mod.em()
-    assert j["n_iter"] == mod.n_iter == max_iter + 1 and j["iter_stop"] == 1
+    assert j["n_iter"] == mod.n_iter <= max_iter + 1          # (-c and the mixture model reach their fixed point to the last bit earlier)
+    assert j["iter_stop"] == int(mod.n_iter == max_iter + 1)
     assert j["logL"] == mod.logL
-    assert np.array_equal(np.fromfile(d + "/q_ref.f64").reshape(I, g.K), mod.q(mod.pindex))
+    assert np.array_equal(np.fromfile(d + "/q_ref.f64").reshape(mod.q(mod.pindex).shape), mod.q(mod.pindex))
     assert np.array_equal(np.fromfile(d + "/p_ref.f64").reshape(g.K, -1), mod.p(mod.pindex))
 
 
