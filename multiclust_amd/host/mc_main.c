@@ -714,33 +714,68 @@ int main(int argc, const char **argv)
 	if ((o.n_gpus > 1 || o.n_streams > 1) && !shardable(&o))
 		fprintf(stderr, "WARNING: --gpus / --streams apply to the admixture model with a fixed number of initialisations; running one fit at a time on one GPU\n");
 
-	if (o.n_repeat > 1 || o.repeat_seconds) {	/* timed_model_estimation (multiclust.c:201-347) */
+	if (o.n_repeat > 1 || o.repeat_seconds) {	/* timed_model_estimation (multiclust.c:201-347): same lines, same statistics */
 		const clock_t start = clock();
-		double sum_ll = 0, sum_ll2 = 0, sum_init = 0, sum_iter = 0, max_ll = -INFINITY, esec = 0;
-		int n = 0, conv = 0, enough = o.repeat_seconds ? 0 : 1, total;
+		double sum_ll = 0, sum_ll2 = 0, sum_init = 0, sum_init2 = 0, sum_iter = 0, sum_iter2 = 0, esec = 0;
+		double sum_aic_K = 0, sum_aic_K2 = 0, sum_bic_K = 0, sum_bic_K2 = 0;
+		double max_ll = -INFINITY, min_aic = 0, min_bic = 0, first_ll = -INFINITY;
+		const double max_ar = 0, max_ll_rand = 0, sum_ar = 0, sum_ar2 = 0;	/* adjusted Rand index: needs -A (refused); its fields stay 0 */
+		int n = 0, conv = 0, reached = 0, first_hit = 0, max_init = 0, max_iter = 0, enough = o.repeat_seconds ? 0 : 1, total;
 		char ab[16];
 		while (n < o.n_repeat || !enough) {
 			if ((rc = estimate_model(&o, &d, &md, &st, 0, &total, NULL))) goto END;
-			if (st.sum.max_logL > max_ll) max_ll = st.sum.max_logL;
+			if (st.sum.n_init > max_init) max_init = st.sum.n_init;
+			if (st.sum.n_max_iter > max_iter) max_iter = st.sum.n_max_iter;
+			if (st.sum.max_logL > max_ll) {
+				mc_model probe;
+				max_ll = st.sum.max_logL;
+				min_aic = st.sum.aic;
+				min_bic = st.sum.bic;
+				memset(&probe, 0, sizeof probe);
+				probe.logL = st.sum.max_logL;	/* converged(opt, mod, first_ll) compares with the model's current logL */
+				if (!mc_converged(&o.em, &probe, first_ll)) { first_ll = st.sum.max_logL; first_hit = n; }
+			}
+			sum_init += st.sum.n_init; sum_init2 += (double)st.sum.n_init * st.sum.n_init;
+			sum_iter += st.sum.n_total_iter; sum_iter2 += (double)st.sum.n_total_iter * st.sum.n_total_iter;
+			sum_aic_K += st.aic_K; sum_aic_K2 += (double)st.aic_K * st.aic_K;
+			sum_bic_K += st.bic_K; sum_bic_K2 += (double)st.bic_K * st.bic_K;
 			sum_ll += st.sum.max_logL; sum_ll2 += st.sum.max_logL * st.sum.max_logL;
-			sum_init += st.sum.n_init; sum_iter += st.sum.n_total_iter;
 			n++;
 			if (st.sum.ever_converged) conv++;
+			if (st.n_targetll_times) reached++;
 			esec = ((double)clock() - start) / CLOCKS_PER_SEC;
 			if (o.em.verbosity > MC_SILENT) {
 				print_model_state(&o, &d, &st, o.max_K, (int)esec, 0);
-				printf(" %f %f %d %d %f NA %d %d %d %u\n", esec, esec / n, 0, conv, max_ll, o.target_revisit, n, o.n_repeat, o.repeat_seconds);
+				printf(" %f %f %d %d %f", esec, esec / n, reached, conv, max_ll);
+				if (o.target_ll) printf(" %f", o.desired_ll); else printf(" NA");
+				printf(" %d %d %d %u\n", o.target_revisit, n, o.n_repeat, o.repeat_seconds);
 			}
 			if (!enough && esec > o.repeat_seconds) enough = 1;
 			if (o.max_repeat_seconds && esec > o.max_repeat_seconds) break;
 		}
-		printf("Data, Method, Model: %s, %s, %s\n", o.filename, accel_abbrev(&o, ab),
-		       o.em.admixture && o.em.eta_constrained ? "admix constrained" : o.em.admixture ? "admix" : "mix");
-		printf("Number of repetitions: %d of %d requested, %d converged\n", n, o.n_repeat, conv);
-		printf("Average time: %fs (total: %fs; target: %u)\n", esec / n, esec, o.repeat_seconds);
-		printf("Average log likelihood: %f (+/- %f)\n", sum_ll / n, sqrt((sum_ll2 - sum_ll * sum_ll / n) / (n - 1)));
-		printf("Maximum log likelihood: %f\n", max_ll);
-		printf("Total initializations, iterations: %d, %d\n", (int)sum_init, (int)sum_iter);
+		if (o.em.verbosity >= MC_SILENT) {
+			printf("Data, Method, Model: %s, %s, %s\n", o.filename, accel_abbrev(&o, ab),
+			       o.em.admixture && o.em.eta_constrained ? "admix constrained" : o.em.admixture ? "admix" : "mix");
+			printf("Run: %e %e %e %e n=%d i=%d u=(%f,%d) w=(%d,%u)\n", o.em.abs_error, o.em.rel_error, o.em.eta_lower_bound,
+			       o.em.p_lower_bound, o.n_init, o.em.n_init_iter, o.desired_ll, o.target_revisit, o.n_repeat, o.repeat_seconds);
+			printf("Number of repetitions: %d of %d requested, %d converged, %d reach target\n", n, o.n_repeat, conv, reached);
+			printf("Average time: %fs (total: %fs; target: %u)\n", esec / n, esec, o.repeat_seconds);
+			printf("Average log likelihood: %f (+/- %f)\n", sum_ll / n, sqrt((sum_ll2 - sum_ll * sum_ll / n) / (n - 1)));
+			printf("Maximum log likelihood: %f first hit at run %d (AIC %f; BIC %f; RAND: %f)\n", max_ll, first_hit, min_aic, min_bic, max_ll_rand);
+			printf("Adjusted RAND: avg = %f +/- %f; max = %f\n", sum_ar / n, sqrt((sum_ar2 - sum_ar * sum_ar / n) / (n - 1)), max_ar);
+			if (o.max_K != o.min_K) {
+				printf("Average K (AIC): %f (+/- %f)\n", sum_aic_K / n, sqrt((sum_aic_K2 - sum_aic_K * sum_aic_K / n) / (n - 1)));
+				printf("Average K (BIC): %f (+/- %f)\n", sum_bic_K / n, sqrt((sum_bic_K2 - sum_bic_K * sum_bic_K / n) / (n - 1)));
+			} else {
+				printf("Total initializations, iterations: %d, %d\n", (int)sum_init, (int)sum_iter);
+				printf("Average initializations: %f (+/- %f) [%e, %e]\n", sum_init / n,
+				       sqrt((sum_init2 - sum_init * sum_init / n) / (n - 1)), sum_init2, sum_init);
+				printf("Average iterations: %f (+/- %f) [%e %e]\n", sum_iter / sum_init,
+				       sqrt((sum_iter2 - sum_iter * sum_iter / sum_init) / (sum_init - 1)), sum_iter2, sum_iter);
+				printf("Maximum initializations: %d\n", max_init);
+				printf("Maximum iterations: %d\n", max_iter);
+			}
+		}
 	} else if ((rc = estimate_model(&o, &d, &md, &st, 0, NULL, NULL))) {
 		goto END;
 	}

@@ -144,3 +144,53 @@ def test_command_line_against_the_reference_program_on_drawn_cases(c, I, L, ploi
             open(b, "w").write("\n".join(without_counts(got_fn)))
             ref_fn, got_fn = a, b
         cli.compare_file(ref_fn, got_fn, atol if not fn.endswith("out.txt") else max(atol * 10, 5e-2 if not exact else 1e-5))
+
+
+def run_both(tmp_path, args, stru):
+    outs = {}
+    for name, exe in (("ref", REFBIN), ("hip", cli.BIN)):
+        d = tmp_path / name
+        d.mkdir()
+        res = subprocess.run([exe, "-f", stru] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=str(d))
+        assert res.returncode == 0, (name, args, res.stderr[-2000:])
+        outs[name] = (cli.CLOCK.sub("HH:MM:SS", res.stdout).strip().split("\n"), d)
+    return outs["ref"], outs["hip"]
+
+
+@pytest.mark.skipif(not os.access(REFBIN, os.X_OK), reason="oracle/_ref/multiclust_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("args,n_files", [
+    ("-a -k 3 -n 2 -r 5 -o myname", 5),          # -o: the five files take the given name (written where the program runs)
+    ("-k 2 -r 5 -n 3 -M -d ./", 5),              # -M: the summary line and the maximum log likelihood, nothing else
+    ("-a -1 2 -2 3 -n 1 -r 5 -d ./", 10),        # a range of K: five files per K
+    ("-a -k 3 -r 5 -n 3 -w n 2", 0),             # -w n 2: the whole estimation twice, run statistics, no files
+    ("-a -1 2 -2 4 -r 9 -n 2 -w n 3 -s 3 -T 20", 0),     # ... over a range of K: the K that AIC and BIC pick, averaged
+    ("-k 3 -r 5 -n 2 -w n 2 -u l -4700", 0),    # ... with a target log likelihood: "reach target" counts
+])
+def test_bookkeeping_options_against_the_reference_program(args, n_files, tmp_path):
+    """the options that only drive maximize_likelihood()'s and timed_model_estimation()'s bookkeeping (multiclust.c:150-345,
+    516-653): same lines, same numbers (plain EM: iteration counts exactly), same files.  Seconds are masked."""
+    stru = os.path.join(cli.GOLD, "data", "multi.stru")
+    (ref_lines, ref_dir), (got_lines, got_dir) = run_both(tmp_path, args.split(), stru)
+    assert len(ref_lines) == len(got_lines), (ref_lines, got_lines)
+    timed = "-w" in args.split()
+    for r, g in zip(ref_lines, got_lines):
+        if timed and r.startswith("Average time:"):
+            assert g.startswith("Average time:")
+            continue
+        rt, gt = r.split(), g.split()
+        assert len(rt) == len(gt), (r, g)
+        if timed and rt[0] == stru:
+            # per-repetition line: print_model_state()'s fields, then cumulative and average seconds, then eight more fields
+            for x in (-10, -9):
+                rt[x] = gt[x] = "seconds"
+        for a, b in zip(rt, gt):
+            try:
+                fa, fb = float(a.strip("(),;[]")), float(b.strip("(),;[]"))
+            except ValueError:
+                assert a == b, (r, g)
+                continue
+            assert abs(fa - fb) <= max(2e-5, 1e-9 * abs(fa)), (r, g)
+    ref_files, got_files = sorted(os.listdir(ref_dir)), sorted(os.listdir(got_dir))
+    assert ref_files == got_files and len(ref_files) == n_files, (ref_files, got_files)
+    for fn in ref_files:
+        cli.compare_file(os.path.join(ref_dir, fn), os.path.join(got_dir, fn), 2e-6 if not fn.endswith("out.txt") else 1e-5)
