@@ -12,6 +12,11 @@
 
 #define MC_MISSING (-9)		/* reference multiclust.h:140 */
 
+/* exit status of the program: the reference returns its error enum from main() (message.h:21-41, multiclust.c:157-163), so a
+ * script that tests $? sees these values */
+enum { MC_EXIT_OK = 0, MC_EXIT_HELP = 1 /* -h: usage() is reached through the error path (multiclust.c:1500-1502) */, MC_EXIT_MEMORY_ALLOCATION = 3, MC_EXIT_FILE_OPEN_ERROR = 5, MC_EXIT_FILE_FORMAT_ERROR = 7,
+       MC_EXIT_INVALID_CMDLINE = 8, MC_EXIT_INVALID_CMD_OPTION = 9, MC_EXIT_INVALID_CMD_ARGUMENT = 10, MC_EXIT_INVALID_USER_SETUP = 11, MC_EXIT_INTERNAL_ERROR = 13 };
+
 typedef struct mc_cli_options {
 	mc_options em;			/* the EM-layer options (mc_host.h) */
 	const char *filename;		/* -f */

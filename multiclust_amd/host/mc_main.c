@@ -85,7 +85,7 @@ static void defaults(mc_cli_options *o)
 	o->n_streams = 1;
 }
 
-#define BAD(msg) do { fprintf(stderr, "ERROR [mc_main.c::parse_options]: %s (argument '%s'); try -h\n", msg, i < argc ? argv[i] : ""); return 2; } while (0)
+#define BAD(msg) do { fprintf(stderr, "ERROR [mc_main.c::parse_options]: %s (argument '%s'); try -h\n", msg, i < argc ? argv[i] : ""); return MC_EXIT_INVALID_CMD_ARGUMENT; } while (0)
 
 static int parse_options(mc_cli_options *o, int argc, const char **argv)
 {
@@ -189,12 +189,14 @@ static int parse_options(mc_cli_options *o, int argc, const char **argv)
 			i--;
 			o->write_files = 0;
 			break;
-		default: BAD("unknown option");
+		default:
+			fprintf(stderr, "ERROR [mc_main.c::parse_options]: unknown option (argument '%s'); try -h\n", argv[i]);
+			return MC_EXIT_INVALID_CMD_OPTION;
 		}
 	}
 	if (!o->filename) {
 		fprintf(stderr, "ERROR [mc_main.c::parse_options]: You must specify the data file with command line option '-f'.  Try '-h' for help.\n");
-		return 2;
+		return MC_EXIT_INVALID_CMDLINE;
 	}
 	return 0;
 }
@@ -322,11 +324,14 @@ static int maximize_likelihood(const mc_cli_options *o, const mc_cli_data *d, co
 {
 	const int K = mod->K, nq = (o->em.admixture && !o->em.eta_constrained) ? d->I * K : K;
 	const int npar = mc_no_parameters(&o->em, md, K);
-	double max_logL_keep = st->sum.max_logL;	/* estimate_model resets it per call, not per K (multiclust.c:377) */
+	/* estimate_model resets the maximum per call, not per K (multiclust.c:377), and nothing resets AIC / BIC: a K whose fits do
+	 * not beat the previous K's maximum reports that K's figures (and writes no files) */
+	const double max_logL_keep = st->sum.max_logL, aic_keep = st->sum.aic, bic_keep = st->sum.bic;
 	double *q = NULL, *p = NULL, *sik = NULL;
 	int *count_K = NULL, rc = 0;
 	mc_summary_reset(&st->sum);
 	st->sum.max_logL = max_logL_keep;
+	if (max_logL_keep > -INFINITY) { st->sum.aic = aic_keep; st->sum.bic = bic_keep; }
 	st->n_targetll_times = 0;
 	st->time_stop = 0;
 	mod->start = clock();
@@ -449,7 +454,7 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 	const int nq = (o->em.admixture && !o->em.eta_constrained) ? d->I * K : K;
 	const int npar = mc_no_parameters(&o->em, md, K);
 	const int keep_mle = !bootstrap && o->n_bootstrap && K == st->null_K;
-	const double max_logL_keep = st->sum.max_logL;
+	const double max_logL_keep = st->sum.max_logL, aic_keep = st->sum.aic, bic_keep = st->sum.bic;
 	shard_worker *w = calloc((size_t)n_dev, sizeof *w);
 	pthread_t *th = calloc((size_t)n_dev, sizeof *th);
 	mc_unit_result *res = calloc((size_t)n_units, sizeof *res);
@@ -494,6 +499,7 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 	/* replay the serial bookkeeping in unit order (multiclust.c:534-560, 618-627) */
 	mc_summary_reset(&st->sum);
 	st->sum.max_logL = max_logL_keep;
+	if (max_logL_keep > -INFINITY) { st->sum.aic = aic_keep; st->sum.bic = bic_keep; }	/* as in maximize_likelihood above */
 	st->time_stop = 0;
 	for (int u = 0; u < n_units; u++) {
 		const double *row = tab[0] + (size_t)u * RES_FIELDS;
@@ -587,7 +593,7 @@ static int estimate_model(const mc_cli_options *o, const mc_cli_data *d, const m
 		if (diff <= 0) {
 			fprintf(stderr, "ERROR [mc_main.c::estimate_model]: Null hypothesis likelihood exceeds alternative hypothesis likelihood.  "
 				"Try increasing number of initializations (command-line option -n)\n");
-			return 3;
+			return MC_EXIT_INTERNAL_ERROR;		/* multiclust.c:437-443 */
 		}
 		if (!bootstrap) st->ts_obs = diff; else st->ts_bs = diff;
 	}
@@ -691,16 +697,16 @@ int main(int argc, const char **argv)
 	run_state st;
 	int rc;
 	defaults(&o);
-	if ((rc = parse_options(&o, argc, argv))) return rc == 1 ? 0 : rc;
+	if ((rc = parse_options(&o, argc, argv))) return rc;	/* -h included: the reference's -h leaves with status 1 */
 	if ((rc = mc_read_structure(&o, &d))) return rc;
 	if (o.em.verbosity >= MC_TALKATIVE)
 		fprintf(stderr, "INFO: Finished reading data: %d %d-ploid individuals at %d loci.\n", d.I, d.ploidy, d.L);
 	mc_data md = { d.I, d.L, d.ploidy, d.uniquealleles, d.geno, NULL };
 	/* synchronize (multiclust.c:807-893) */
-	if (mc_synchronize(&o.em, &md)) return 2;
-	if (d.I < o.max_K) { fprintf(stderr, "ERROR: Maximum number of clusters (%d) (set with command-line argument -k) cannot exceed the number of individuals (%d)\n", o.max_K, d.I); return 2; }
-	if (o.n_bootstrap && o.max_K <= 1) { fprintf(stderr, "ERROR: When bootstrapping, maximum K (%d) (set with command-line argument -k) must exceed 1.\n", o.max_K); return 2; }
-	if (o.min_K > o.max_K) { fprintf(stderr, "ERROR: Minimum K (%d) must not exceed maximum K (%d).\n", o.min_K, o.max_K); return 2; }
+	if (mc_synchronize(&o.em, &md)) return MC_EXIT_INVALID_USER_SETUP;
+	if (d.I < o.max_K) { fprintf(stderr, "ERROR: Maximum number of clusters (%d) (set with command-line argument -k) cannot exceed the number of individuals (%d)\n", o.max_K, d.I); return MC_EXIT_INVALID_USER_SETUP; }
+	if (o.n_bootstrap && o.max_K <= 1) { fprintf(stderr, "ERROR: When bootstrapping, maximum K (%d) (set with command-line argument -k) must exceed 1.\n", o.max_K); return MC_EXIT_INVALID_USER_SETUP; }
+	if (o.min_K > o.max_K) { fprintf(stderr, "ERROR: Minimum K (%d) must not exceed maximum K (%d).\n", o.min_K, o.max_K); return MC_EXIT_INVALID_USER_SETUP; }
 	if (!o.target_ll && !o.target_revisit && !o.em.n_seconds && !o.n_init) o.n_init = 1;
 	if (!o.em.n_rand_em_init) o.em.initialization_procedure = MC_INIT_NOTHING;	/* -m 0 (multiclust.c:1549-1550) */
 	memset(&st, 0, sizeof st);

@@ -17,12 +17,16 @@
 #include <time.h>
 #include <unistd.h>
 
+/* prints and returns the exit status the reference's reader returns for this kind of failure (message.h:21-41: out of memory 3,
+ * file cannot be opened 5, anything wrong with its contents 7) */
 static int fail(const char *fn, int line, const char *msg, const char *arg)
 {
 	fprintf(stderr, "ERROR [mc_reader.c::%s(%d)]: ", fn, line);
 	fprintf(stderr, msg, arg ? arg : "");
 	fprintf(stderr, "\n");
-	return 1;
+	if (!strncmp(msg, "out of memory", 13)) return MC_EXIT_MEMORY_ALLOCATION;
+	if (!strncmp(msg, "could not open", 14)) return MC_EXIT_FILE_OPEN_ERROR;
+	return MC_EXIT_FILE_FORMAT_ERROR;
 }
 #define FAIL(msg, arg) fail(__func__, __LINE__, msg, arg)
 
@@ -225,11 +229,11 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 		}
 		p = q + 1;
 	}
-	int rc = 1;
+	int rc = MC_EXIT_FILE_FORMAT_ERROR;
 	PHASE("file into memory");
 	memset(dat, 0, sizeof *dat);
 	dat->ploidy = opt->ploidy;
-	if (nlines < 3) { FAIL("file '%s' has no data lines", opt->filename); goto DONE; }
+	if (nlines < 3) { rc = FAIL("file '%s' has no data lines", opt->filename); goto DONE; }
 
 	int L = count_tokens(ls[0], le[0]);		/* read_file.c:56 */
 	if (opt->R_format) L -= 2;
@@ -239,7 +243,7 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 		char *t = next_token(&c, le[1], &len);
 		if (t && len == 2 && !strncmp(t, "-1", 2)) first = 2;
 	}
-	if (nlines < first + 2) { FAIL("file '%s' has fewer than two data lines", opt->filename); goto DONE; }
+	if (nlines < first + 2) { rc = FAIL("file '%s' has fewer than two data lines", opt->filename); goto DONE; }
 	{	/* interleaved iff the first two data lines carry different names (read_file.c:89-90) */
 		char *c1 = ls[first], *c2 = ls[first + 1];
 		size_t l1, l2;
@@ -248,22 +252,22 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 	}
 	const int pl = dat->ploidy;
 	int ncol = count_tokens(ls[first + 1], le[first + 1]) - 2;	/* allele columns of a data line (read_file.c:100) */
-	if (dat->interleaved && ncol != L && ncol != pl * L) { FAIL("number of allele columns in '%s' is not a multiple of ploidy", opt->filename); goto DONE; }
-	if (!dat->interleaved && ncol != L) { FAIL("number of locus names in '%s' does not match the alleles of the first individual (check -R)", opt->filename); goto DONE; }
+	if (dat->interleaved && ncol != L && ncol != pl * L) { rc = FAIL("number of allele columns in '%s' is not a multiple of ploidy", opt->filename); goto DONE; }
+	if (!dat->interleaved && ncol != L) { rc = FAIL("number of locus names in '%s' does not match the alleles of the first individual (check -R)", opt->filename); goto DONE; }
 	if (dat->interleaved && ncol == L) L /= pl;	/* header names every allele column (read_file.c:115-116) */
 	/* read_file.c:119: I = (remaining lines) + 2 - skip_line_two.  With the "-1" line present the reference counts one
 	 * data line too few: it drops the last individual of an interleaved file and rejects a non-interleaved one whose
 	 * line count was right.  Kept, so that the same file gives the same fit. */
 	size_t ndata = nlines - first - (first == 2 ? 1 : 0);
-	if (!dat->interleaved && (ndata % (size_t)pl)) { FAIL("number of lines in '%s' is not a multiple of ploidy", opt->filename); goto DONE; }
+	if (!dat->interleaved && (ndata % (size_t)pl)) { rc = FAIL("number of lines in '%s' is not a multiple of ploidy", opt->filename); goto DONE; }
 	const int I = dat->interleaved ? (int)ndata : (int)(ndata / (size_t)pl);
 	const int nhap = I * pl;
-	if (L <= 0 || I <= 0) { FAIL("no loci or no individuals in '%s'", opt->filename); goto DONE; }
+	if (L <= 0 || I <= 0) { rc = FAIL("no loci or no individuals in '%s'", opt->filename); goto DONE; }
 	dat->I = I; dat->L = L;
 	dat->IL = malloc(sizeof(int) * (size_t)nhap * L);
 	dat->names = calloc((size_t)I, sizeof *dat->names);
 	dat->locale = calloc((size_t)I, sizeof *dat->locale);
-	if (!dat->IL || !dat->names || !dat->locale) { FAIL("out of memory%s", NULL); goto DONE; }
+	if (!dat->IL || !dat->names || !dat->locale) { rc = FAIL("out of memory%s", NULL); goto DONE; }
 
 	for (size_t ln = 0; ln < ndata; ln++) {
 		char *c = ls[first + ln], *end = le[first + ln];
@@ -271,7 +275,7 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 		char *name = next_token(&c, end, &len);
 		size_t llen, nlen = len;
 		char *loc = next_token(&c, end, &llen);
-		if (!name || !loc) { FAIL("line without name/locale columns in '%s'", opt->filename); goto DONE; }
+		if (!name || !loc) { rc = FAIL("line without name/locale columns in '%s'", opt->filename); goto DONE; }
 		if (dat->interleaved || !(ln % (size_t)pl)) {
 			dat->names[i] = dup_token(name, nlen);
 			int found = -1;				/* add_to_string_set: order of first appearance */
@@ -279,7 +283,7 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 				if (strlen(dat->pops[n]) == llen && !strncmp(dat->pops[n], loc, llen)) { found = n; break; }
 			if (found < 0) {
 				char **pops2 = realloc(dat->pops, sizeof *dat->pops * (size_t)(dat->numpops + 1));
-				if (!pops2) { FAIL("out of memory%s", NULL); goto DONE; }
+				if (!pops2) { rc = FAIL("out of memory%s", NULL); goto DONE; }
 				dat->pops = pops2;
 				dat->pops[dat->numpops] = dup_token(loc, llen);
 				found = dat->numpops++;
@@ -304,8 +308,8 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 			if (th[t]) pthread_join(th[t], NULL);
 			if (!perr) perr = jobs[t].err;
 		}
-		if (perr == RD_SHORT_LINE) { FAIL("failed to read a locus in file '%s'.  Check option -R.", opt->filename); goto DONE; }
-		if (perr) { FAIL("non-integer allele in file '%s'", opt->filename); goto DONE; }
+		if (perr == RD_SHORT_LINE) { rc = FAIL("failed to read a locus in file '%s'.  Check option -R.", opt->filename); goto DONE; }
+		if (perr) { rc = FAIL("non-integer allele in file '%s'", opt->filename); goto DONE; }
 	}
 	PHASE("parse");
 	dat->i_p = calloc((size_t)dat->numpops, sizeof *dat->i_p);
@@ -316,7 +320,7 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 	dat->L_alleles = calloc((size_t)L, sizeof *dat->L_alleles);
 	dat->toff = calloc((size_t)L + 1, sizeof *dat->toff);
 	dat->geno = malloc((size_t)I * L * pl);
-	if (!dat->uniquealleles || !dat->L_alleles || !dat->toff || !dat->geno) { FAIL("out of memory%s", NULL); goto DONE; }
+	if (!dat->uniquealleles || !dat->L_alleles || !dat->toff || !dat->geno) { rc = FAIL("out of memory%s", NULL); goto DONE; }
 	{
 		const int nt = n_threads((size_t)nhap * (size_t)L);
 		locus_job jobs[64];
@@ -334,8 +338,8 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 			if (jobs[t].missing_data) dat->missing_data = 1;
 			if (jobs[t].M > dat->M) dat->M = jobs[t].M;
 		}
-		if (lerr == RD_TOO_MANY) { FAIL("a locus of '%s' has more than 254 alleles", opt->filename); goto DONE; }
-		if (lerr) { FAIL("out of memory%s", NULL); goto DONE; }
+		if (lerr == RD_TOO_MANY) { rc = FAIL("a locus of '%s' has more than 254 alleles", opt->filename); goto DONE; }
+		if (lerr) { rc = FAIL("out of memory%s", NULL); goto DONE; }
 	}
 	for (int l = 0; l < L; l++) dat->toff[l + 1] = dat->toff[l] + dat->uniquealleles[l];
 	dat->T = dat->toff[L];
