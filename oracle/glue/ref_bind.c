@@ -12,7 +12,7 @@
  * not); tests/test_gpu_refbind.py runs it on the command lines of the reference's own goldens.  No GPU: every fit fails.
  *
  * The libc rand() stream stays the program's one random stream: the reference seeds it (srand in parse_options,
- * multiclust.c:1592-1596) and anything else in the program may keep drawing from it; an initialisation borrows its
+ * multiclust.c:1592-1596) and parametric_bootstrap() (bootstrap.c) keeps drawing from it; an initialisation borrows its
  * state (initstate/setstate expose glibc's TYPE_3 table: word 0 = 5 * rear + type, words 1..31 = the table), lets the device
  * draw the partition from it and hands the advanced state back.
  */
@@ -27,6 +27,9 @@ static struct {
 	uint8_t *flat;		/* observed genotype, allele indices */
 	mc_options mo;
 	mc_data md;
+	uint8_t *sim;		/* the bootstrap replicate parametric_bootstrap() left in dat->ILM, as allele copies */
+	uint64_t sim_hash;
+	int on_sim;
 	mc_model *mm;
 	int K;
 	double *sik;
@@ -44,13 +47,34 @@ static void unbind(void)
 	B.mm = NULL;
 }
 
+/* counts -> copies in allele order (the EM path reads counts only; the random partition of the admixture model keeps reading the
+ * observed copies, mc_data::init_geno, as rnd_init.c:471 keeps reading dat->IL) */
+static uint64_t copies_from_counts(const data *dat, uint8_t *g)
+{
+	uint64_t h = 1469598103934665603ull;
+	for (int i = 0; i < dat->I; i++)
+		for (int l = 0; l < dat->L; l++) {
+			int a = 0;
+			for (int m = 0; m < dat->uniquealleles[l]; m++)
+				for (int c = 0; c < dat->ILM[i][l][m] && a < dat->ploidy; c++) {
+					g[((size_t)i * dat->L + l) * dat->ploidy + a++] = (uint8_t)m;
+					h = (h ^ (uint64_t)(m + 1)) * 1099511628211ull;
+				}
+			for (; a < dat->ploidy; a++) g[((size_t)i * dat->L + l) * dat->ploidy + a] = MCHIP_MISSING;
+			h = (h ^ 255u) * 1099511628211ull;
+		}
+	return h;
+}
+
 static void bind(options *opt, data *dat, model *mod)
 {
 	int fresh = 0;
 	if (opt->pfile || opt->qfile) bind_fatal("starting values from files (-p/-q) are not bound");
 	if (B.dat != dat) {
 		unbind();
-		free(B.flat);
+		free(B.flat); free(B.sim);
+		B.sim = NULL;
+		B.on_sim = 0;
 		B.flat = mcamd_flatten_genotypes(dat);
 		if (!B.flat) bind_fatal("out of memory");
 		B.dat = dat;
@@ -58,14 +82,25 @@ static void bind(options *opt, data *dat, model *mod)
 		atexit(unbind);
 		fresh = 1;
 	}
-	/* parametric_bootstrap() swaps dat->ILM (bootstrap.c:35-41).  Not bound here: the reference's own -b run aborts in its
-	 * second model (free(): invalid pointer, tests/test_gpu_cli.py), so there is nothing to compare an executed binding with;
-	 * mcamd_bootstrap_model() is the documented call and the replicate generator is pinned in tests/test_gpu_bootstrap.py */
-	if (dat->ILM != B.ilm) bind_fatal("bootstrap replicates (-b) are not bound in this test program");
+	/* -b: parametric_bootstrap() (bootstrap.c, the reference's own generator, drawing from the program's rand() stream) swaps
+	 * dat->ILM for its replicate array once and refills it per replicate (bootstrap.c:35-41): the replicate is uploaded like any
+	 * data set (last row, second form) */
+	const int on_sim = dat->ILM != B.ilm;
 	const uint8_t *geno = B.flat;
+	if (on_sim) {
+		if (!B.sim && !(B.sim = malloc((size_t)dat->I * dat->L * dat->ploidy))) bind_fatal("out of memory");
+		const uint64_t h = copies_from_counts(dat, B.sim);
+		if (!B.on_sim || h != B.sim_hash) fresh = 1;	/* another replicate */
+		B.sim_hash = h;
+		geno = B.sim;
+	} else if (B.on_sim) {
+		fresh = 1;
+	}
+	B.on_sim = on_sim;
 	/* after the reference's synchronize() (multiclust.c:807): opt->lower_bound is already MIN(bound, 0.5 / I / ploidy), and
 	 * mc_synchronize applies the same rule again without changing it */
 	if (mcamd_options(opt, dat, geno, opt->lower_bound, &B.mo, &B.md)) bind_fatal("options do not carry over");
+	B.md.init_geno = on_sim ? B.flat : NULL;
 	if (fresh || !B.mm || B.K != mod->K) {
 		unbind();
 		const char *dev = getenv("MCAMD_DEVICE");

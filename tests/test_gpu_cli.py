@@ -112,8 +112,9 @@ def test_cli_k_range_and_quiet_mode(tmp_path):
 
 
 def test_cli_bootstrap_device_host_and_sharded_agree(tmp_path, monkeypatch):
-    """-b: the reference's own binary aborts in its second model ("free(): invalid pointer"), so there is no golden
-    stdout; the replicate generator itself is pinned to the reference's parametric_bootstrap() in
+    """-b: no committed golden (on the data with missing values first tried, the reference's own binary aborts in its second
+    model, "free(): invalid pointer"; on data without, it runs, and tests/test_gpu_cli_differential.py compares whole -b runs
+    with it live); the replicate generator itself is pinned to the reference's parametric_bootstrap() in
     tests/test_bootstrap_cpu.py / test_gpu_bootstrap.py.  Here: the run completes, and three ways of running it print
     the same thing: replicates generated on the device, replicates drawn on the host and uploaded, and whole replicates
     sharded over devices (rehearsed with one device: worker thread, rand() jump-ahead per replicate, captured stdout,

@@ -7,9 +7,11 @@ side.  The binary travels with the tree (the sources do not); here it runs the c
 (tests/golden/cli_*: what the unmodified reference printed and wrote for the same arguments).
 
 Left out: the goldens on data with missing values (the reference's reader leaves the phantom allele slot uninitialised and
-the program aborts in free() depending on the length of its path strings, oracle/make_fixtures.py), -P/-Q starting values and
--b (the reference's own -b run aborts in its second model): the reference-side driver code that fails there is not ours to fix.
-Skipped where the binary is absent."""
+the program aborts in free() depending on the length of its path strings, oracle/make_fixtures.py) and -P/-Q starting values:
+the reference-side driver code that fails there is not ours to fix.  -b has no committed golden; the second test runs the bound
+program beside the unmodified one (oracle/_ref/multiclust_ref, which travels too) on bootstrap command lines: the replicates
+come from the reference's own parametric_bootstrap() in both, drawn from the one rand() stream that the bound program lends to
+the device for its initialisations in between.  Skipped where the binaries are absent."""
 import os
 
 import pytest
@@ -33,3 +35,41 @@ BOUND = os.path.join(cli.ROOT, "oracle", "_ref", "multiclust_ref_hip")
 def test_reference_program_on_the_hip_path_reproduces_its_own_goldens(case, atol, tmp_path, monkeypatch):
     monkeypatch.setattr(cli, "BIN", BOUND)
     cli.test_cli_matches_reference_binary(case, atol, tmp_path)
+
+
+REFBIN = os.path.join(cli.ROOT, "oracle", "_ref", "multiclust_ref")
+
+
+@pytest.mark.skipif(not (os.access(BOUND, os.X_OK) and os.access(REFBIN, os.X_OK)), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("args", [
+    "-a -k 3 -n 2 -b 3 -r 9",                    # H0 and HA on the observed data, three replicates, two initialisations each
+    "-a -k 4 -n 1 -b 2 -r 4 -s 3 -T 30",
+    "-k 3 -n 2 -b 2 -r 4",                       # mixture model
+    "-p 4 -a -k 3 -n 1 -b 2 -r 11 tetra",
+])
+def test_bound_program_beside_the_unmodified_one_on_bootstrap_runs(args, tmp_path):
+    import subprocess
+    args = args.split()
+    stru = os.path.join(cli.GOLD, "data", "tetra.stru" if args[-1] == "tetra" else "multi.stru")
+    args = [a for a in args if a != "tetra"]
+    lines = {}
+    for name, exe in (("ref", REFBIN), ("bound", BOUND)):
+        d = tmp_path / name
+        d.mkdir()
+        res = subprocess.run([exe, "-f", stru, "-d", os.path.join(str(d), "")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             text=True, timeout=600, cwd=str(d))
+        assert res.returncode == 0, (name, res.stderr[-2000:])
+        lines[name] = cli.CLOCK.sub("HH:MM:SS", res.stdout).strip().split("\n")
+    assert len(lines["ref"]) == len(lines["bound"])
+    exact = "-s" not in args
+    for r, g in zip(lines["ref"], lines["bound"]):
+        assert cli.NUM.sub("#", r) == cli.NUM.sub("#", g), (r, g)
+        toks = cli.NUM.findall(r)
+        for tok, x, y in zip(toks, [float(t) for t in toks], [float(t) for t in cli.NUM.findall(g)]):
+            if "." not in tok and "e" not in tok and abs(x) < 1e6:
+                if exact:
+                    assert x == y, (r, g)                     # iteration counts, initialisations, K
+            else:
+                assert abs(x - y) <= max(2e-5, 1e-6 * abs(x)) + (0 if exact else 5e-2), (r, g)
+    assert any(l.startswith("p-value to reject H0") for l in lines["bound"])
+
