@@ -152,6 +152,7 @@ def run_both(tmp_path, args, stru, status=0):
         d = tmp_path / name
         d.mkdir()
         res = subprocess.run([exe, "-f", stru] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=str(d))
+        open(str(tmp_path / (name + ".stderr")), "w").write(res.stderr)
         assert res.returncode == status, (name, args, res.returncode, res.stderr[-2000:])
         outs[name] = (cli.CLOCK.sub("HH:MM:SS", res.stdout).strip().split("\n"), d)
     return outs["ref"], outs["hip"]
@@ -212,3 +213,42 @@ def test_bootstrap_whose_null_model_fits_as_well_as_the_alternative_ends_like_th
     for r, g in zip(ref_lines, got_lines):
         assert cli.NUM.sub("#", r) == cli.NUM.sub("#", g), (r, g)
 
+
+
+@pytest.mark.skipif(not os.access(REFBIN, os.X_OK), reason="oracle/_ref/multiclust_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("variant,args", [
+    ("interleaved", "-a -k 3 -n 1 -r 5 -d ./"),        # one line per individual, detected from the first two names (read_file.c:84-95)
+    ("R", "-a -k 3 -n 1 -r 5 -R -d ./"),               # -R: the header names the two leading columns too (read_file.c:58-59)
+    ("plain", "-a -k 3 -n 1 -r 5 -T 6 -v 4 -d ./"),    # -v 4: one line per iteration on stderr (em_alg.c:123-136)
+    ("plain", "-a -k 3 -n 1 -r 5 -T 8 -v 4 -s 3 -d ./"),       # ... naming the accelerated steps
+    ("plain", "-a -k 3 -n 1 -r 5 -T 8 -v 4 -s 5 -d ./"),       # ... quasi-Newton with two secant pairs: "Q2"
+    ("plain", "-k 3 -n 1 -r 5 -T 6 -v 4 -d ./"),               # mixture model
+])
+def test_input_formats_and_iteration_lines_against_the_reference_program(variant, args, tmp_path):
+    src = os.path.join(cli.GOLD, "data", "multi_interleaved.stru" if variant == "interleaved" else "multi.stru")
+    stru = src
+    if variant == "R":
+        rows = open(src).read().split("\n")
+        stru = str(tmp_path / "multi_R.stru")
+        open(stru, "w").write("\n".join(["id pop " + rows[0]] + rows[1:]))
+    (ref_lines, ref_dir), (got_lines, got_dir) = run_both(tmp_path, args.split(), stru)
+    assert len(ref_lines) == len(got_lines)
+    for r, g in zip(ref_lines, got_lines):
+        assert cli.NUM.sub("#", r) == cli.NUM.sub("#", g), (r, g)
+        for x, y in zip(cli.NUM.findall(r), cli.NUM.findall(g)):
+            assert abs(float(x) - float(y)) <= max(2e-5, 1e-6 * abs(float(x))), (r, g)
+    if "-v" in args.split():
+        import re
+        it = re.compile(r"^\s*\d+ \(")
+        ref_it = [l for l in open(str(tmp_path / "ref.stderr")).read().split("\n") if it.match(l)]
+        got_it = [l for l in open(str(tmp_path / "hip.stderr")).read().split("\n") if it.match(l)]
+        assert len(ref_it) == len(got_it) >= 4, (ref_it, got_it)
+        for r, g in zip(ref_it, got_it):
+            assert cli.NUM.sub("#", r) == cli.NUM.sub("#", g), (r, g)            # "   3 (S3): # (delta): #"
+            for x, y in zip(cli.NUM.findall(r), cli.NUM.findall(g)):
+                assert abs(float(x) - float(y)) <= max(0.0051, 2e-5 * abs(float(x))), (r, g)     # two decimals / five significant digits
+    files = sorted(os.listdir(ref_dir))
+    assert files == sorted(os.listdir(got_dir)) and len(files) in (4, 5)
+    for fn in files:
+        if not fn.endswith("_mix_popq.popq"):
+            cli.compare_file(os.path.join(ref_dir, fn), os.path.join(got_dir, fn), 2e-6 if not fn.endswith("out.txt") else 1e-5)
