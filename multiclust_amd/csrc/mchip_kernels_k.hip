@@ -747,9 +747,12 @@ __global__ __launch_bounds__(QBLOCK, sparse_min_waves(PL, ACCUM)) void k_individ
 #endif
 					}
 					if (SAFE) {
-						prod *= t[b];
+						/* projection off: an extrapolated point may have entries outside [0, 1] and t < 0 in a cell that carries a
+						 * copy; the reference's log(t) is NaN there and ends the run (em_alg.c:106-110).  Two such factors
+						 * must not cancel in the product: a negative t poisons it */
+						prod *= t[b] < 0.0 ? __builtin_nan("") : t[b];
 						rescale(prod, ex);
-						prod *= t[b + 1];
+						prod *= t[b + 1] < 0.0 ? __builtin_nan("") : t[b + 1];
 						rescale(prod, ex);
 					} else {
 						prod *= pp;
@@ -794,7 +797,7 @@ __global__ __launch_bounds__(QBLOCK, sparse_min_waves(PL, ACCUM)) void k_individ
 #pragma unroll
 						for (int k = 0; k < KSP; k++) acc[k] = __builtin_fma(pc[k], r, acc[k]);
 					}
-					prod *= miss ? 1.0 : t;
+					prod *= miss ? 1.0 : (t < 0.0 ? __builtin_nan("") : t);		/* as above: a negative t must end in NaN */
 					rescale(prod, ex);
 				}
 			}

@@ -31,13 +31,6 @@ def draw_cases(n, seed):
         extra = rnd.choice(["", "", "-n 2", "-T 9", "-i 3", "-n 2 -T 30"])
         I, L = rnd.randrange(24, 90), rnd.randrange(20, 120)
         more = rnd.choice(["", "", "", "--projection", "--bound 1e-5", "-E 1e-6", "-e 1e-9 -E 0"])
-        if more == "--projection" and scheme:
-            # projection off AND an extrapolated step: entries of P leave [0, 1] (the reference prints p = -0.000206), both programs
-            # carry on until the log of a negative number ends the run with "nan", and which iteration that is depends on the last
-            # bits (seven such cases in a soak: the reference stopped in its second initialisation, this build in the first; where
-            # both finish, the reference writes three of its five files because log() left EDOM in the errno its writers test).
-            # Plain EM with --projection is compared; the accelerated combination is not
-            more = ""
         extra = (extra + " " + more).strip()
         if scheme and "-T" not in extra:
             # an accelerated run left to converge takes hundreds of cycles, and its path is sensitive to the last bit of every sum
@@ -120,6 +113,14 @@ def test_command_line_against_the_reference_program_on_drawn_cases(c, I, L, ploi
         ours = [f for f in ours if f != popq[0]]
         files = [f for f in files if f != popq[0]]
         assert len(files) == 4
+    elif "--projection" in extra.split() and scheme and len(files) == 3:
+        # projection off AND an extrapolated step: entries of P leave [0, 1] (the reference prints p = -0.000206), a cell's
+        # t = sum_k q_k p_k can turn negative, and log() of it leaves EDOM in the errno the reference's popq / indivq writers test
+        # after their malloc (write_file.c:417,424,505,512): those two files are then missing.  The run itself is compared:
+        # where the log likelihood of the extrapolated point is NaN both programs fall back to the EM iterate, and a NaN in an
+        # E step ends both at the same iteration (the kernels' log-product must not let two negative factors cancel: found here)
+        assert all(not f.endswith(("popq", "indivq")) for f in files)
+        ours = [f for f in ours if not f.endswith(("popq", "indivq"))]
     else:
         assert len(files) == 5
     assert files == ours, (files, ours)
