@@ -2,7 +2,7 @@
 own sources compiled by oracle/Makefile in the build container; the binary travels with the tree, the sources do not) and
 multiclust_amd/bin/multiclust run the same freshly generated STRUCTURE files with the same arguments; stdout lines (iteration
 counts exactly for plain EM) and the five output files must agree as in tests/test_gpu_cli.py.  Where test_gpu_cli.py compares
-with committed outputs of twelve command lines, this draws its cases: ploidy 1-4, K 2-6, admixture / -c / mixture, every
+with committed outputs of twelve command lines, this draws its cases: ploidy 1-6, K 2-9, up to 36 alleles per locus, admixture / -c / mixture, every
 acceleration scheme, -n 2 (two initialisations from one rand() stream), -i, -T, --projection, --bound, -E / -e, and 3 % missing
 values in a quarter of the cases (a case is skipped when the reference's uninitialised allele slot spoils ITS run).
 Skipped where the reference binary is absent."""
@@ -24,8 +24,8 @@ def draw_cases(n, seed):
     rnd = random.Random(seed)
     out = []
     for c in range(n):
-        ploidy = rnd.choice([1, 2, 2, 2, 3, 4])
-        K = rnd.choice([2, 3, 3, 4, 5, 6])
+        ploidy = rnd.choice([1, 2, 2, 2, 3, 4, 6])
+        K = rnd.choice([2, 3, 3, 4, 5, 6, 9])
         model = rnd.choice(["-a", "-a", "-a", "-a -c", ""])           # "" = mixture
         scheme = rnd.choice([0, 0, 1, 2, 3, 3, 4, 5, 6]) if model != "" or rnd.random() < 0.5 else 0
         extra = rnd.choice(["", "", "-n 2", "-T 9", "-i 3", "-n 2 -T 30"])
@@ -50,8 +50,10 @@ def test_command_line_against_the_reference_program_on_drawn_cases(c, I, L, ploi
     from make_fixtures import write_stru, phantom_slots
     seed, missing = seed // 10, (seed % 10) / 100.0        # 0 or 3 % of the allele copies missing
     rnd = random.Random(seed)
+    # one case in five has loci with 36 alleles: beyond the 32 rows per locus of the LDS tiles, the dense fallback kernels run
+    alleles = [2, 2, 3, 4, 5, 12, 36] if seed % 5 == 0 else [2, 2, 3, 4, 5]
     stru = str(tmp_path / ("d%d.stru" % c))
-    write_stru(stru, I, L, max(2, K - 1), ploidy, [rnd.choice([2, 2, 3, 4, 5]) for _ in range(L)], seed=seed, missing=missing)
+    write_stru(stru, I, L, max(2, K - 1), ploidy, [rnd.choice(alleles) for _ in range(L)], seed=seed, missing=missing)
     phantom = phantom_slots(stru, ploidy) if missing else {}
     args = ["-p", str(ploidy), "-k", str(K), "-r", str(seed % 9973 + 1)] + model.split() + extra.split()
     if "-n" not in args:
@@ -124,11 +126,12 @@ def test_command_line_against_the_reference_program_on_drawn_cases(c, I, L, ploi
     else:
         assert len(files) == 5
     assert files == ours, (files, ours)
-    if "-c" in model.split() and not exact:
+    if "-c" in model.split():
         # shared mixing proportions: the likelihood is a function of sum_k eta_k p_klm alone, so the maximum is a ridge of (eta, P)
-        # with one log likelihood.  Plain EM walks to the same point of it as the reference (exact cases above); an extrapolated
-        # step (here -s 4 from a nearly stationary point: both programs print -6123.259218 after 5 iterations) lands elsewhere
-        # on the ridge by the last bits of its step size.  The log likelihood lines were compared; the parameters are not comparable
+        # with one log likelihood, and along it EM neither contracts nor expands a difference: last-bit differences of the sums
+        # drift (a plain-EM run to -E 1e-6 ended with eta_0 = 0.2044 against 0.1946, same log likelihood to the printed digit,
+        # same iteration counts; an extrapolated step from a nearly stationary point lands anywhere on the ridge).  The lines
+        # with the log likelihoods and iteration counts were compared above; the parameters of this model are not comparable
         return
     for fn in files:
         ref_fn, got_fn = os.path.join(ref_dir, fn), os.path.join(got_dir, fn)
