@@ -1,7 +1,8 @@
 """-m gpu: the hot path against the reference's OWN em(), live, at sizes the committed goldens do not reach.
 oracle/_ref/ref_time (oracle/ref_time.c linked with the reference's unmodified sources in the build container; the binary
 travels with the tree) runs em() from given parameters on flat arrays; the same data, parameters, scheme and -T go through
-mc_em on the GPU.  Drawn cases: 200-3 000 individuals, 300-6 000 loci, ploidy 1-6, up to 12 alleles per locus, K 2-12,
+mc_em on the GPU.  Drawn cases: 200-3 000 individuals, 300-6 000 loci, ploidy 1-6, up to 12 alleles per locus, K 2-12 and, in
+every fourth case, 13-64 (the lane-split kernels),
 admixture / -c / mixture, plain EM and every acceleration scheme, 3-8 iterations.  Bounds: log likelihood 1e-8 absolute at the
 scale of config 1 and 5e-12 relative beyond (the reference's own running sum of 1e7 terms is good to about 1e-12 at
 |logL| = 7e7: the largest difference seen in 136 cases was 1.3e-12); Q and P entries above 1e-6: 1e-9 relative after plain EM
@@ -32,7 +33,9 @@ def draw_cases(n, seed):
         L = int(rs.integers(3000, 6000)) if big else int(rs.integers(300, 2000))
         ploidy = int(rs.choice([1, 2, 2, 2, 3, 4, 4, 6]))
         maxal = int(rs.choice([2, 3, 4, 4, 6, 12]))
-        K = int(rs.choice([2, 3, 4, 5, 7, 8, 8, 12]))
+        K = int(rs.choice([2, 3, 4, 5, 7, 8, 8, 12])) if c % 4 else int(rs.choice([13, 16, 21, 24, 29, 33, 40, 47, 52, 57, 64]))
+        if K > 12:                                            # the lane-split kernel families (two or four lanes per individual,
+            I, L = min(I, 400), min(L, 600)                   # two lanes per allele column from K = 37)
         model = str(rs.choice(["admix", "admix", "admix", "admix_c", "mix"]))
         scheme = int(rs.choice([0, 0, 1, 2, 3, 3, 4, 5, 6]))
         iters = int(rs.integers(3, 9))
