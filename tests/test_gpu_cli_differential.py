@@ -89,7 +89,8 @@ def test_command_line_against_the_reference_program_on_drawn_cases(c, I, L, ploi
     if "--projection" in args and scheme and len(ref_lines) != len(got_lines):
         # projection off and extrapolated steps: parameters outside [0, 1].  17 of 18 such runs in the soaks agree line for line
         # (NaN log likelihoods of refused points included); in one the reference's 30th iteration was NaN and this build's was
-        # not, after 29 identical ones -- a sum over entries of both signs that cancels to zero in one summation order only
+        # not, after 29 identical ones (scripts/diag/diffcase.sh 56 53 500; which of the reference's operations produced it
+        # was not pursued: the iterate already had entries of both signs)
         nan = ["nan" in open(str(tmp_path / (n + ".stderr"))).read() for n in ("ref", "hip")]
         if any(nan):
             pytest.skip("projection off, extrapolated steps: the two programs met NaN at different iterations")
