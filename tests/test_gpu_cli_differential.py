@@ -266,3 +266,32 @@ def test_input_formats_and_iteration_lines_against_the_reference_program(variant
     for fn in files:
         if not fn.endswith("_mix_popq.popq"):
             cli.compare_file(os.path.join(ref_dir, fn), os.path.join(got_dir, fn), 2e-6 if not fn.endswith("out.txt") else 1e-5)
+
+
+@pytest.mark.skipif(not os.access(REFBIN, os.X_OK), reason="oracle/_ref/multiclust_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("I,L,ploidy,K,args", [
+    (400, 3000, 2, 8, "-a -n 1 -r 12 -T 60"),               # 60 plain EM iterations of a fit with several workgroups per pass
+    (300, 2500, 2, 8, "-a -n 1 -r 12 -s 3 -T 30"),          # SQUAREM-3 in the batched device loop
+    (250, 1500, 4, 7, "-a -n 2 -r 8 -T 25"),                # tetraploid, two initialisations
+])
+def test_larger_fits_against_the_reference_program(I, L, ploidy, K, args, tmp_path):
+    """the same comparison at sizes beyond the drawn cases (the reference's reader sorts all haplotypes per locus: a few seconds here)"""
+    from make_fixtures import write_stru
+    rnd = random.Random(I * L)
+    stru = str(tmp_path / "big.stru")
+    write_stru(stru, I, L, K - 1, ploidy, [rnd.choice([2, 3, 4]) for _ in range(L)], seed=I + L)
+    (ref_lines, ref_dir), (got_lines, got_dir) = run_both(tmp_path, ["-p", str(ploidy), "-k", str(K), "-d", "./"] + args.split(), stru)
+    assert len(ref_lines) == len(got_lines)
+    exact = "-s" not in args.split()
+    for r, g in zip(ref_lines, got_lines):
+        assert cli.NUM.sub("#", r) == cli.NUM.sub("#", g), (r, g)
+        toks = cli.NUM.findall(r)
+        for tok, x, y in zip(toks, [float(t) for t in toks], [float(t) for t in cli.NUM.findall(g)]):
+            if "." not in tok and "e" not in tok and abs(x) < 1e6:
+                assert x == y, (r, g)
+            else:
+                assert abs(x - y) <= max(2e-5, 1e-6 * abs(x)) + (0 if exact else 5e-2), (r, g)
+    files = sorted(os.listdir(ref_dir))
+    assert files == sorted(os.listdir(got_dir)) and len(files) == 5
+    for fn in files:
+        cli.compare_file(os.path.join(ref_dir, fn), os.path.join(got_dir, fn), (2e-6 if exact else 5e-3) if not fn.endswith("out.txt") else (1e-5 if exact else 5e-2))
