@@ -300,15 +300,17 @@ static int cli_initialize(const mc_cli_options *o, const mc_cli_data *d, const m
 	mod->converged = 0;
 	if (o->em.accel_scheme) mod->pindex = mod->tindex = mod->findex = 0;
 	if (!q || !p) rc = MCHIP_ERR_ALLOC;
-	if (!rc && (!fq || !fp)) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: cannot open '%s'\n", fq ? o->pfile : o->qfile); rc = 2; }
+	if (!rc && (!fq || !fp)) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: cannot open '%s'\n", fq ? o->pfile : o->qfile); rc = MC_EXIT_FILE_OPEN_ERROR; }
 	for (int x = 0; !rc && x < nq; x++)
-		if (fscanf(fq, "%lf", &q[x]) != 1) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: format of '%s'\n", o->qfile); rc = 2; }
+		if (fscanf(fq, "%lf", &q[x]) != 1) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: format of '%s'\n", o->qfile); rc = MC_EXIT_FILE_FORMAT_ERROR; }
 	if (!rc) rc = mc_model_get_p(mod, mod->tindex, p);
 	for (int l = 0; !rc && l < d->L; l++)
 		for (int k = 0; !rc && k < K; k++) {
 			double v;
-			if (fscanf(fp, "%lf", &v) != 1) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: format of '%s'\n", o->pfile); rc = 2; break; }
-			if (d->uniquealleles[l] < 2) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: -P needs two alleles at every locus\n"); rc = 2; break; }
+			if (fscanf(fp, "%lf", &v) != 1) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: format of '%s'\n", o->pfile); rc = MC_EXIT_FILE_FORMAT_ERROR; break; }
+			/* (the reference stores 1 - v in the locus's second allele slot whether or not there is one, read_file.c:950: a
+			 * monomorphic locus makes it write past its allocation; refused here) */
+			if (d->uniquealleles[l] < 2) { fprintf(stderr, "ERROR [mc_main.c::cli_initialize]: -P needs two alleles at every locus\n"); rc = MC_EXIT_INVALID_USER_SETUP; break; }
 			p[(size_t)k * d->T + d->toff[l]] = v;
 			p[(size_t)k * d->T + d->toff[l] + 1] = 1 - v;
 		}
