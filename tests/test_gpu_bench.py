@@ -153,3 +153,14 @@ def test_cpu_baseline_legs_on_small_workloads(workload, extra):
     assert cb["reference_extrapolated"]["kind"] == "extrapolation"
     if have_ref:
         assert 1 < cb["ns_per_cell"] < 500        # (i, allele column, k) cell and iteration: 4-11 ns on a GPU box's host, 30-65 on the build container
+
+
+def test_a_reference_binary_that_does_not_run_costs_the_line_nothing():
+    """oracle/_ref/ref_time is built in one container and run in another: if it cannot run there, cpu_baseline falls back to
+    the oracle and says why; the result line is still printed."""
+    out = run_bench(["--workload", "c1", "--steps", "4", "--warmup", "1", "--settle", "0", "--stability", "0", "--no-secondary",
+                     "--cpu-budget", "0.3", "--ref-budget", "0.3"], {"MC_BENCH_REF_TIME": "/bin/false"})
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and "the reference leg failed" in cb["reference"]
+    assert out["value"] > 0
+
