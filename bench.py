@@ -414,7 +414,12 @@ def reference_leg(w, ua_s, geno_s, q0, p0, accel, iters, procs, budget_s, device
             cmd = [REF_TIME, d, str(I), str(Lr), str(p), str(K), str(iters - 1), "--"] + args
             # independent units (c4, c5): the reference's scaling model is one process per unit (multiclust.c:143-145)
             runs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(procs)]
-            outs = [r.communicate() for r in runs]
+            try:
+                outs = [r.communicate(timeout=max(120.0, 20.0 * seconds)) for r in runs]
+            except subprocess.TimeoutExpired:
+                for r in runs:
+                    r.kill()
+                raise SystemExit("cpu_baseline: the reference run did not finish in time")
             if any(r.returncode for r in runs):
                 raise SystemExit("cpu_baseline: the reference run failed: %s" % outs[0][1][-400:])
             res = [json.loads(o[0]) for o in outs]
