@@ -232,6 +232,8 @@ def test_mixture_vs_oracle_synthetic(ctx, I, L, K):
 
 
 @pytest.mark.parametrize("I,L,K,ploidy,maxal,missing,opts", [
+    (150000, 9, 4, 2, 3, 0.0, {}),                                  # extreme aspect ratios: nine loci, one block of 8 and a remainder ...
+    (5, 300000, 3, 2, 4, 0.01, {}),                                 # ... and five individuals: one partly filled workgroup per locus chunk
     (70, 150, 3, 2, 40, 0.0, {}),                                   # > 32 alleles at a locus: dense fallback kernels
     (300, 40, 3, 2, 120, 0.0, {}),                                  # > 64 alleles: projection with byte flags instead of a 64-bit mask
     (90, 210, 4, 1, 3, 0.02, {}),                                   # haploid
