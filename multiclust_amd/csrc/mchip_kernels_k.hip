@@ -204,13 +204,16 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_pass(mchip_pass_args a)
 #pragma unroll
 					for (int k = 0; k < K; k++) acc[k] = __builtin_fma(q[k], r, acc[k]);
 				}
-				/* n log t as log of a product: t^n */
+				/* n log t as log of a product: t^n.  SAFE (projection off): a negative t in a cell that carries copies is
+				 * NaN in the reference's log and must not square itself away in a homozygote (found on a 36-allele locus:
+				 * tests/test_gpu_cli_differential.py) */
 				if (LL) {
+					const double tl = (SAFE && t < 0.0) ? __builtin_nan("") : t;
 					if (PL == 2) {
-						prod *= (n >= 1) ? t : 1.0;
-						prod *= (n >= 2) ? t : 1.0;
+						prod *= (n >= 1) ? tl : 1.0;
+						prod *= (n >= 2) ? tl : 1.0;
 					} else {
-						for (int b = 1; b <= pl; b++) prod *= (n >= b) ? t : 1.0;
+						for (int b = 1; b <= pl; b++) prod *= (n >= b) ? tl : 1.0;
 					}
 				}
 				if (LL && SAFE) {

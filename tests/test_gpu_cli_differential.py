@@ -20,6 +20,22 @@ pytestmark = pytest.mark.gpu
 REFBIN = os.path.join(cli.ROOT, "oracle", "_ref", "multiclust_ref")
 
 
+def run_program(cmd, cwd, timeout=120):
+    """One launch in about 4 000 of these soaks -- a 60-locus mixture fit that takes 0.3 s -- did not return within 300 s, on a box
+    where everything before and after ran at normal speed; run again with -v 4 it finished at once with the reference's output
+    line for line (scripts/diag/hang184.py).  Not reproduced, cause unknown (nothing in the host code waits on anything but
+    pthread_join and stream synchronisation).  A launch that exceeds the limit is repeated once, with a warning in the report;
+    a second timeout fails the test."""
+    for attempt in (1, 2):
+        try:
+            return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=cwd)
+        except subprocess.TimeoutExpired:
+            if attempt == 2:
+                raise
+            import warnings
+            warnings.warn("no return within %d s, launched again: %s" % (timeout, " ".join(cmd)))
+
+
 def draw_cases(n, seed):
     rnd = random.Random(seed)
     out = []
@@ -66,8 +82,7 @@ def test_command_line_against_the_reference_program_on_drawn_cases(c, I, L, ploi
     for name, exe in (("ref", REFBIN), ("hip", cli.BIN)):
         d = tmp_path / name
         d.mkdir()
-        res = subprocess.run([exe, "-f", stru, "-d", os.path.join(str(d), "")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                             text=True, timeout=300, cwd=str(d))
+        res = run_program([exe, "-f", stru, "-d", os.path.join(str(d), "")] + args, str(d))
         open(str(tmp_path / (name + ".stdout")), "w").write(res.stdout)        # kept for scripts/diag/diffcase.sh
         open(str(tmp_path / (name + ".stderr")), "w").write(" ".join(args) + "\n" + res.stderr)
         if name == "ref" and phantom:
@@ -86,14 +101,6 @@ def test_command_line_against_the_reference_program_on_drawn_cases(c, I, L, ploi
         assert res.returncode == 0, (name, args, res.stderr[-2000:])
         outs[name] = (cli.CLOCK.sub("HH:MM:SS", res.stdout).strip().split("\n"), d)
     (ref_lines, ref_dir), (got_lines, got_dir) = outs["ref"], outs["hip"]
-    if "--projection" in args and scheme and len(ref_lines) != len(got_lines):
-        # projection off and extrapolated steps: parameters outside [0, 1].  17 of 18 such runs in the soaks agree line for line
-        # (NaN log likelihoods of refused points included); in one the reference's 30th iteration was NaN and this build's was
-        # not, after 29 identical ones (scripts/diag/diffcase.sh 56 53 500; which of the reference's operations produced it
-        # was not pursued: the iterate already had entries of both signs)
-        nan = ["nan" in open(str(tmp_path / (n + ".stderr"))).read() for n in ("ref", "hip")]
-        if any(nan):
-            pytest.skip("projection off, extrapolated steps: the two programs met NaN at different iterations")
     assert len(ref_lines) == len(got_lines), (args, ref_lines, got_lines)
     # plain EM: same iteration counts, files to 6 decimals.  Accelerated schemes: the extrapolated path amplifies last-bit
     # differences (tests/test_gpu_host_driver.py: test_squarem_path_depends_on_summation_order), so counts and values get the
@@ -130,7 +137,8 @@ def test_command_line_against_the_reference_program_on_drawn_cases(c, I, L, ploi
         # t = sum_k q_k p_k can turn negative, and log() of it leaves EDOM in the errno the reference's popq / indivq writers test
         # after their malloc (write_file.c:417,424,505,512): those two files are then missing.  The run itself is compared:
         # where the log likelihood of the extrapolated point is NaN both programs fall back to the EM iterate, and a NaN in an
-        # E step ends both at the same iteration (the kernels' log-product must not let two negative factors cancel: found here)
+        # E step ends both at the same iteration (the kernels' log-product must not let two negative factors cancel -- the two
+        # copies of a homozygote included: both found here, in the sparse and in the dense kernels)
         assert all(not f.endswith(("popq", "indivq")) for f in files)
         ours = [f for f in ours if not f.endswith(("popq", "indivq"))]
     else:
@@ -165,7 +173,7 @@ def run_both(tmp_path, args, stru, status=0):
     for name, exe in (("ref", REFBIN), ("hip", cli.BIN)):
         d = tmp_path / name
         d.mkdir()
-        res = subprocess.run([exe, "-f", stru] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=str(d))
+        res = run_program([exe, "-f", stru] + args, str(d), timeout=300)
         open(str(tmp_path / (name + ".stderr")), "w").write(res.stderr)
         assert res.returncode == status, (name, args, res.returncode, res.stderr[-2000:])
         outs[name] = (cli.CLOCK.sub("HH:MM:SS", res.stdout).strip().split("\n"), d)
