@@ -1,6 +1,8 @@
 """-m gpu: parity at BASELINE.json's full sizes through size-independent properties (and the oracle where it finishes
 in seconds): config 2 (2 000 x 20 000, K = 5) against the oracle on the whole problem, config 3 (10 000 x 100 000,
 M_l <= 4, K = 8) against exact identities of the E/M steps and against the oracle on a slice of individuals."""
+import os
+
 import numpy as np
 import pytest
 
@@ -19,6 +21,44 @@ def fast_geno(I, L, ploidy, maxal, seed, chunk=500):
         i1 = min(I, i0 + chunk)
         geno[i0:i1] = (rng.integers(0, 1 << 20, size=(i1 - i0, L, ploidy), dtype=np.int32) % ua[None, :, None]).astype(np.uint8)
     return ua, geno
+
+
+REF_TIME = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_time")
+
+
+@pytest.mark.skipif(not os.access(REF_TIME, os.X_OK), reason="oracle/_ref/ref_time not built")
+@pytest.mark.parametrize("scheme,iters", [(0, 3), (3, 4)])
+def test_config2_full_size_against_the_reference_em(scheme, iters, tmp_path):
+    """BASELINE.json's configs[1] whole -- 2 000 diploid individuals x 20 000 biallelic loci, K = 5 -- through the reference's own
+    em() (oracle/_ref/ref_time: its unmodified sources, 3.2 GB of diklm, a few seconds per iteration on one host core) and through
+    mc_em from the same parameters: plain EM (the configuration's own -s 0) and two SQUAREM-3 cycles.  north_star's bounds are
+    1e-6 relative on Q / P and 1e-8 absolute on the log likelihood at config-1 scale; here |logL| = 5e7, where the reference's
+    own running sum of 8e7 terms is good to about 1e-12 relative: 5e-12 is asked, and 1e-9 on the parameters."""
+    import json
+    import subprocess
+    from multiclust_amd import host
+    I, L, K = 2000, 20000, 5
+    ua, geno = make_dataset(I, L, K, ploidy=2, max_alleles=2, seed=20250119, chunk=128)
+    lb = min(1e-8, 0.5 / (I * 2))
+    q0, p0 = random_params(I, ua, K, seed=4, lower_bound=lb)
+    d = str(tmp_path)
+    np.ascontiguousarray(ua, dtype=np.int32).tofile(d + "/ua.i32")
+    geno.tofile(d + "/geno.u8")
+    q0.tofile(d + "/q0.f64")
+    p0.tofile(d + "/p0.f64")
+    res = subprocess.run([REF_TIME, d, str(I), str(L), "2", str(K), str(iters - 1), "--", "-f", "x", "-a", "-k", str(K)] +
+                         (["-s", str(scheme)] if scheme else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-1000:]
+    ref = json.loads(res.stdout)
+    fit = host.Fit(ua, geno, K, admixture=1, accel_scheme=scheme, verbosity=1, abs_error=1e-300, rel_error=0.0, max_iter=iters - 1)
+    fit.set_params(q0, p0)
+    fit.em()
+    assert fit.mod.n_iter == ref["n_iter"] == iters
+    assert abs(fit.mod.logL - ref["logL"]) <= 5e-12 * abs(ref["logL"]), (fit.mod.logL, ref["logL"])
+    gq, gp = fit.get_q(fit.mod.pindex), fit.get_p(fit.mod.pindex)
+    fit.close()
+    np.testing.assert_allclose(gq, np.fromfile(d + "/q_ref.f64").reshape(I, K), rtol=1e-9 if not scheme else 1e-7, atol=1e-13)
+    np.testing.assert_allclose(gp, np.fromfile(d + "/p_ref.f64").reshape(K, -1), rtol=1e-9 if not scheme else 1e-7, atol=1e-13)
 
 
 def check_simplex(q, p, ua, lb):
