@@ -61,6 +61,41 @@ def test_config2_full_size_against_the_reference_em(scheme, iters, tmp_path):
     np.testing.assert_allclose(gp, np.fromfile(d + "/p_ref.f64").reshape(K, -1), rtol=1e-9 if not scheme else 1e-7, atol=1e-13)
 
 
+@pytest.mark.skipif(not os.access(REF_TIME, os.X_OK), reason="oracle/_ref/ref_time not built")
+@pytest.mark.parametrize("I,L,ploidy,K,scheme,iters,what", [
+    (10000, 2500, 2, 8, 3, 4, "config 3 / 4: every individual, the first 2 500 of its 100 000 loci, two SQUAREM-3 cycles"),
+    (5000, 4000, 4, 8, 0, 3, "config 5, alternative model: every individual, the first 4 000 of its 50 000 loci, plain EM"),
+    (5000, 4000, 4, 7, 0, 3, "config 5, null model"),
+])
+def test_locus_slices_of_configs_3_and_5_against_the_reference_em(I, L, ploidy, K, scheme, iters, what, tmp_path):
+    """the reference cannot hold configs 3-5 (0.5 TB of diklm at config 3): every individual and as many loci as fit a few GB go
+    through its em() and through mc_em from the same parameters.  Bounds as in the config-2 test."""
+    import json
+    import subprocess
+    from multiclust_amd import host
+    ua, geno = fast_geno(I, L, ploidy, 4, seed=I + L + K)
+    lb = min(1e-8, 0.5 / (I * ploidy))
+    q0, p0 = random_params(I, ua, K, seed=6, lower_bound=lb)
+    d = str(tmp_path)
+    np.ascontiguousarray(ua, dtype=np.int32).tofile(d + "/ua.i32")
+    geno.tofile(d + "/geno.u8")
+    q0.tofile(d + "/q0.f64")
+    p0.tofile(d + "/p0.f64")
+    res = subprocess.run([REF_TIME, d, str(I), str(L), str(ploidy), str(K), str(iters - 1), "--", "-f", "x", "-a", "-k", str(K)] +
+                         (["-s", str(scheme)] if scheme else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-1000:]
+    ref = json.loads(res.stdout)
+    fit = host.Fit(ua, geno, K, admixture=1, accel_scheme=scheme, verbosity=1, abs_error=1e-300, rel_error=0.0, max_iter=iters - 1)
+    fit.set_params(q0, p0)
+    fit.em()
+    assert fit.mod.n_iter == ref["n_iter"] == iters
+    assert abs(fit.mod.logL - ref["logL"]) <= 5e-12 * abs(ref["logL"]), (fit.mod.logL, ref["logL"])
+    gq, gp = fit.get_q(fit.mod.pindex), fit.get_p(fit.mod.pindex)
+    fit.close()
+    np.testing.assert_allclose(gq, np.fromfile(d + "/q_ref.f64").reshape(I, K), rtol=1e-9 if not scheme else 1e-7, atol=1e-13)
+    np.testing.assert_allclose(gp, np.fromfile(d + "/p_ref.f64").reshape(K, -1), rtol=1e-9 if not scheme else 1e-7, atol=1e-13)
+
+
 def check_simplex(q, p, ua, lb):
     assert np.all(q >= lb * (1 - 1e-12)) and np.all(p >= lb * (1 - 1e-12))
     np.testing.assert_allclose(q.sum(axis=1), 1.0, rtol=0, atol=1e-12)
