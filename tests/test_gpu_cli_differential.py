@@ -27,8 +27,9 @@ SIZE_LIMIT = SIZE ** 3                                   # (a hexaploid 328 x 23
 def run_program(cmd, cwd, timeout=None):
     """One launch in about 4 000 of these soaks -- a 60-locus mixture fit that takes 0.3 s -- did not return within 300 s, on a box
     where everything before and after ran at normal speed; run again with -v 4 it finished at once with the reference's output
-    line for line (scripts/diag/hang184.py).  Not reproduced, cause unknown (nothing in the host code waits on anything but
-    pthread_join and stream synchronisation).  A launch that exceeds the limit is repeated once, with a warning in the report;
+    line for line (scripts/diag/hang184.py), and 1 500 launches of that very fit in a loop all returned within 0.4 s
+    (scripts/diag/hang_stress.sh, which records the threads' wait channels of a launch that does not).  Not reproduced, cause
+    unknown (nothing in the host code waits on anything but pthread_join and stream synchronisation).  A launch that exceeds the limit is repeated once, with a warning in the report;
     a second timeout fails the test."""
     timeout = timeout or 120 * SIZE_LIMIT
     for attempt in (1, 2):
