@@ -56,6 +56,7 @@ struct mchip_context {
 	uint8_t *d_col_allele;
 	uint8_t *d_gtA, *d_gtS, *d_gtC;
 	int count_bits, has_missing;
+	int first_empty;	/* first individual without a single observed copy, or -1 (see set_model_impl) */
 	unsigned long long nnz_cells, n_copies;	/* cells with n_ic > 0, non-missing allele copies (mchip_data_counts) */
 	int counts_valid;
 	size_t geno_bytes_A, geno_bytes_S;
@@ -1404,6 +1405,7 @@ int mchip_create(mchip_context **out, int device)
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MCHIP_ERR_NO_DEVICE;
 	if (device < 0 || device >= n) return MCHIP_ERR_INVALID;
 	mchip_context *ctx = new mchip_context();
+	ctx->first_empty = -1;
 	ctx->device = device;
 	ctx->err[0] = 0;
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1597,6 +1599,14 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	int rc = set_shape(ctx, I, L, ploidy, ua);
 	if (rc) return rc;
 	const size_t raw_bytes = (size_t)I * L * ploidy;
+	/* an individual whose every copy is missing (one pass that stops at each individual's first observed copy: O(I) on real data) */
+	ctx->first_empty = -1;
+	for (int i = 0; i < I && ctx->first_empty < 0; i++) {
+		const uint8_t *row = geno + (size_t)i * L * ploidy;
+		size_t x = 0;
+		while (x < (size_t)L * ploidy && row[x] == MCHIP_MISSING) x++;
+		if (x == (size_t)L * ploidy) ctx->first_empty = i;
+	}
 	if ((rc = stream_buffer(ctx))) return rc;
 	HIPCHK(hipMemcpyAsync(ctx->d_draw, geno, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
 	return install_raw(ctx, ctx->d_draw);
@@ -1620,6 +1630,7 @@ int mchip_copy_genotypes(mchip_context *ctx, const mchip_context *src)
 	}
 	if (ctx->has_missing != src->has_missing) drop_graphs(ctx);
 	ctx->has_missing = src->has_missing;
+	ctx->first_empty = src->first_empty;
 	ctx->count_bits = src->count_bits;
 	ctx->counts_valid = src->counts_valid;
 	ctx->nnz_cells = src->nnz_cells;
@@ -1721,6 +1732,16 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	if (K < 1) return fail(ctx, MCHIP_ERR_INVALID, "K must be >= 1%s", nullptr);
 	if (K > MCHIP_MAX_K) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "K > MCHIP_MAX_K is not built%s", nullptr);
 	if (n_secants < 0 || n_secants > MCHIP_MAX_SECANTS) return fail(ctx, MCHIP_ERR_INVALID, "n_secants out of range%s", nullptr);
+	if (admixture && !eta_constrained && ctx->first_empty >= 0) {
+		/* The reference gives such an individual mixing proportions 0 / 0 = NaN (em_alg.c:685-690) and carries on: it adds to no
+		 * sum there, because zero-count cells are skipped one by one.  Here its NaN row would reach its neighbours through the
+		 * reciprocal four cells share and through q * 0 in the N-side sums: said at once instead of "nan" three iterations on
+		 * (tests/test_gpu_ref_live.py; carrying such rows the reference's way is listed in DESIGN.md section 8) */
+		char who[32];
+		snprintf(who, sizeof who, "%d", ctx->first_empty);
+		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "individual %s (counting from 0) has no observed allele copy: its mixing proportions are "
+			    "undefined (the reference carries NaN for it); remove it from the data set or use -c", who);
+	}
 	/* the element-per-thread kernels over parameters take one work-item per entry of P or Q */
 	if ((size_t)K * ctx->T >= ((size_t)1 << 31) || (size_t)K * ctx->I >= ((size_t)1 << 31))
 		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "K*T or K*I of 2^31 or more is not supported%s", nullptr);
@@ -2485,6 +2506,7 @@ int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const
 	 * (the reference's dat->IL stays in place across parametric_bootstrap calls, bootstrap.c:35-41) */
 	int rc = set_shape(ctx, I, L, ploidy, ua, 1);
 	if (rc) return rc;
+	ctx->first_empty = -1;		/* every copy of a generated data set is drawn */
 	const size_t n_copies = (size_t)I * L * ploidy;
 	rng_window base;
 	size_t n_chunks, n_blocks;

@@ -10,8 +10,10 @@
  * (read_file.c:518,577: O((I*ploidy)^2 * L), 13 minutes for config 2), which would turn a 20-second timing sample into
  * hours.  Instead the fields of `data` the EM path reads (em_alg.c, accel_em.c, log_likelihood.c, simplex.c: I, L, M,
  * ploidy, uniquealleles, L_alleles, ILM; allocate_model_for_k(): max_M) are filled here from the same (ua, geno) arrays
- * the HIP path gets, and the starting parameters are written into slot 0 (where initialize_model() leaves its own).  No
- * missing data in the sample (the synthetic bench workloads have none), so no phantom allele slots.
+ * the HIP path gets, and the starting parameters are written into slot 0 (where initialize_model() leaves its own).  A
+ * missing copy (0xFF) adds to no count, as in the reference's reader; the allele slot that reader appends to a locus with
+ * missing values -- a column no copy ever matches -- is just another entry of ua[] if the caller wants it (the EM layer reads
+ * L_alleles only to ask whether its FIRST entry is the missing code, em_alg.c / multiclust.c:1274: it never is here).
  *
  * usage: ref_time <dir> <I> <L> <ploidy> <K> <max_iter> -- <multiclust argv: -f x [-a [-c]] -k K [-s n]>
  *   <dir>/ua.i32 [L], geno.u8 [I][L][ploidy] (allele index), q0.f64 [I][K] ([K] with -c and for the mixture model), p0.f64 [K][T]
@@ -103,7 +105,8 @@ int main(int argc, const char **argv)
 			dat->ILM[i][l] = c;
 			for (int a = 0; a < ploidy; a++) {
 				uint8_t m = geno[((size_t)i * L + l) * ploidy + a];
-				if (m >= ua[l]) die("allele index out of range (missing data is not supported here)");
+				if (m == 0xFF) { dat->missing_data = 1; continue; }	/* a missing copy counts nowhere (read_file.c:600-620) */
+				if (m >= ua[l]) die("allele index out of range");
 				c[m]++;
 			}
 		}

@@ -3,7 +3,8 @@ oracle/_ref/ref_time (oracle/ref_time.c linked with the reference's unmodified s
 travels with the tree) runs em() from given parameters on flat arrays; the same data, parameters, scheme and -T go through
 mc_em on the GPU.  Drawn cases: 200-3 000 individuals, 300-6 000 loci, ploidy 1-6, up to 12 alleles per locus, K 2-12 and, in
 every fourth case, 13-64 (the lane-split kernels),
-admixture / -c / mixture, plain EM and every acceleration scheme, 3-8 iterations.  Bounds: log likelihood 1e-8 absolute at the
+admixture / -c / mixture, plain EM and every acceleration scheme, 3-8 iterations, a quarter of the cases with 3 % and a quarter
+with 20 % missing copies.  Bounds: log likelihood 1e-8 absolute at the
 scale of config 1 and 5e-12 relative beyond (the reference's own running sum of 1e7 terms is good to about 1e-12 at
 |logL| = 7e7: the largest difference seen in 136 cases was 1.3e-12); Q and P entries above 1e-6: 1e-9 relative after plain EM
 iterations -- three orders inside north_star's 1e-6 -- and north_star's 1e-6 itself after accelerated cycles, whose
@@ -47,7 +48,10 @@ def draw_cases(n, seed):
 @pytest.mark.parametrize("c,I,L,ploidy,maxal,K,model,scheme,iters,seed",
                          draw_cases(int(os.environ.get("MC_LIVE_CASES", "16")), 20250117 + int(os.environ.get("MC_LIVE_SEED", "0"))))
 def test_mc_em_against_the_reference_em_on_drawn_shapes(c, I, L, ploidy, maxal, K, model, scheme, iters, seed, tmp_path):
-    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=seed)
+    missing = [0.0, 0.0, 0.03, 0.2][seed % 4]
+    ua, geno = make_dataset(I, L, max(K, 2), ploidy=ploidy, max_alleles=maxal, seed=seed, missing=missing)
+    if missing and seed % 8 < 6:      # as the reference's reader shapes it: one more allele slot, which nothing matches, at loci with missing copies
+        ua = (ua + (geno == 0xFF).any(axis=(0, 2)).astype(np.int32)).astype(np.int32)
     admixture, constrained = int(model != "mix"), int(model == "admix_c")
     lb = min(1e-8, 0.5 / (I * ploidy))                                     # multiclust.c:812-815
     q0, p0 = random_params(I, ua, K, seed=seed + 1, lower_bound=lb)
@@ -89,3 +93,44 @@ def test_mc_em_against_the_reference_em_on_drawn_shapes(c, I, L, ploidy, maxal, 
         big = want > 1e-6
         assert np.max(np.abs(got - want)[big] / want[big]) <= (1e-6 if scheme else 1e-9)
         assert np.max(np.abs(got - want)[~big], initial=0.0) <= (1e-10 if scheme else 1e-12)
+
+
+@pytest.mark.skipif(not os.access(REF_TIME, os.X_OK), reason="oracle/_ref/ref_time not built (needs /root/reference at build time)")
+def test_an_individual_without_a_single_observed_copy(tmp_path):
+    """two individuals of thirty have every copy missing.  The reference gives them mixing proportions 0 / 0 = NaN (em_alg.c:685-690)
+    after the first M step and carries on -- they add to no sum there, zero-count cells being skipped one by one -- so its fit of the
+    others is unharmed (checked here: NaN in exactly those rows).  This build cannot carry a NaN row (it would reach its neighbours
+    through the reciprocal four cells share and through q * 0 in the N-side sums) and says so when the model is set, naming the
+    individual, instead of ending in "nan" three iterations later (which is how this case was found); with shared mixing proportions
+    (-c) and under the mixture model such individuals are harmless and the fits agree with the reference."""
+    I, L, ploidy, K = 30, 40, 2, 3
+    ua, geno = make_dataset(I, L, K, ploidy=ploidy, max_alleles=4, seed=5, missing=0.05)
+    geno[4] = 0xFF
+    geno[20] = 0xFF
+    ua = (ua + (geno == 0xFF).any(axis=(0, 2)).astype(np.int32)).astype(np.int32)
+    lb = min(1e-8, 0.5 / (I * ploidy))
+    q0, p0 = random_params(I, ua, K, seed=6, lower_bound=lb)
+    d = str(tmp_path)
+    ua.tofile(d + "/ua.i32")
+    geno.tofile(d + "/geno.u8")
+    p0.tofile(d + "/p0.f64")
+    for flags, q_start in ((["-a"], q0), (["-a", "-c"], q0[0] / q0[0].sum()), ([], q0[0] / q0[0].sum())):
+        np.ascontiguousarray(q_start).tofile(d + "/q0.f64")
+        res = subprocess.run([REF_TIME, d, str(I), str(L), str(ploidy), str(K), "5", "--", "-f", "x"] + flags + ["-k", str(K)],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        assert res.returncode == 0 and res.stdout.strip(), res.stderr[-500:]
+        ref = json.loads(res.stdout)
+        q_ref, p_ref = np.fromfile(d + "/q_ref.f64").reshape(q_start.shape), np.fromfile(d + "/p_ref.f64").reshape(K, -1)
+        kw = dict(admixture=int("-a" in flags), eta_constrained=int("-c" in flags), verbosity=1, abs_error=1e-300, rel_error=0.0, max_iter=5)
+        if flags == ["-a"]:
+            assert np.isnan(q_ref[[4, 20]]).all() and not np.isnan(np.delete(q_ref, [4, 20], axis=0)).any() and not np.isnan(p_ref).any()
+            with pytest.raises(Exception, match="mc_model_create failed"):
+                host.Fit(ua, geno, K, **kw)
+            continue
+        fit = host.Fit(ua, geno, K, **kw)
+        fit.set_params(np.ascontiguousarray(q_start), p0)
+        fit.em()
+        assert fit.mod.n_iter == ref["n_iter"] and abs(fit.mod.logL - ref["logL"]) <= 1e-8
+        np.testing.assert_allclose(fit.get_q(fit.mod.pindex), q_ref, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(fit.get_p(fit.mod.pindex), p_ref, rtol=1e-9, atol=1e-13)
+        fit.close()
