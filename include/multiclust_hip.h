@@ -63,6 +63,11 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy,
 /* Counted on the device when a data set is installed: cells (i, l, m) with ILM[i][l][m] > 0 -- the cells the reference's E step
  * visits (em_alg.c:338-342) and the unit the flop count of the path is stated in -- and non-missing allele copies. */
 int mchip_data_counts(mchip_context *ctx, uint64_t *nonempty_cells, uint64_t *allele_copies);
+/* Individuals of the data set held without a single observed allele copy (returns how many; *first = the first one's index or
+ * -1).  Under the admixture model with individual mixing proportions the reference gives such a row 0 / 0 = NaN in its first M
+ * step (em_alg.c:685-690) and, NaN then sitting in the secants, its step size is NaN and every accelerated cycle falls back to
+ * its EM iterate (accel_em.c:58-62): mchip_get_q reports the row as NaN, the host side (mc_step_size) does the falling back. */
+int mchip_empty_individuals(const mchip_context *ctx, int *first);
 /* the data set currently held, back in the upload form [I][L][ploidy] */
 int mchip_get_genotypes(mchip_context *ctx, uint8_t *geno);
 /*

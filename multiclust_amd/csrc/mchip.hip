@@ -56,7 +56,9 @@ struct mchip_context {
 	uint8_t *d_col_allele;
 	uint8_t *d_gtA, *d_gtS, *d_gtC;
 	int count_bits, has_missing;
-	int first_empty;	/* first individual without a single observed copy, or -1 (see set_model_impl) */
+	int first_empty;	/* first individual without a single observed copy, or -1 */
+	std::vector<int> empty_rows;	/* all of them: their mixing proportions are 0 / 0 in the reference (em_alg.c:685-690) */
+	int empty_rows_nan;	/* an M step has run since the parameters were set: mchip_get_q reports those rows as the reference has them */
 	unsigned long long nnz_cells, n_copies;	/* cells with n_ic > 0, non-missing allele copies (mchip_data_counts) */
 	int counts_valid;
 	size_t geno_bytes_A, geno_bytes_S;
@@ -1601,12 +1603,15 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	const size_t raw_bytes = (size_t)I * L * ploidy;
 	/* an individual whose every copy is missing (one pass that stops at each individual's first observed copy: O(I) on real data) */
 	ctx->first_empty = -1;
-	for (int i = 0; i < I && ctx->first_empty < 0; i++) {
+	ctx->empty_rows.clear();
+	ctx->empty_rows_nan = 0;
+	for (int i = 0; i < I; i++) {
 		const uint8_t *row = geno + (size_t)i * L * ploidy;
 		size_t x = 0;
 		while (x < (size_t)L * ploidy && row[x] == MCHIP_MISSING) x++;
-		if (x == (size_t)L * ploidy) ctx->first_empty = i;
+		if (x == (size_t)L * ploidy) ctx->empty_rows.push_back(i);
 	}
+	if (!ctx->empty_rows.empty()) ctx->first_empty = ctx->empty_rows[0];
 	if ((rc = stream_buffer(ctx))) return rc;
 	HIPCHK(hipMemcpyAsync(ctx->d_draw, geno, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
 	return install_raw(ctx, ctx->d_draw);
@@ -1631,6 +1636,8 @@ int mchip_copy_genotypes(mchip_context *ctx, const mchip_context *src)
 	if (ctx->has_missing != src->has_missing) drop_graphs(ctx);
 	ctx->has_missing = src->has_missing;
 	ctx->first_empty = src->first_empty;
+	ctx->empty_rows = src->empty_rows;
+	ctx->empty_rows_nan = 0;
 	ctx->count_bits = src->count_bits;
 	ctx->counts_valid = src->counts_valid;
 	ctx->nnz_cells = src->nnz_cells;
@@ -1732,16 +1739,6 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	if (K < 1) return fail(ctx, MCHIP_ERR_INVALID, "K must be >= 1%s", nullptr);
 	if (K > MCHIP_MAX_K) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "K > MCHIP_MAX_K is not built%s", nullptr);
 	if (n_secants < 0 || n_secants > MCHIP_MAX_SECANTS) return fail(ctx, MCHIP_ERR_INVALID, "n_secants out of range%s", nullptr);
-	if (admixture && !eta_constrained && ctx->first_empty >= 0) {
-		/* The reference gives such an individual mixing proportions 0 / 0 = NaN (em_alg.c:685-690) and carries on: it adds to no
-		 * sum there, because zero-count cells are skipped one by one.  Here its NaN row would reach its neighbours through the
-		 * reciprocal four cells share and through q * 0 in the N-side sums: said at once instead of "nan" three iterations on
-		 * (tests/test_gpu_ref_live.py; carrying such rows the reference's way is listed in DESIGN.md section 8) */
-		char who[32];
-		snprintf(who, sizeof who, "%d", ctx->first_empty);
-		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "individual %s (counting from 0) has no observed allele copy: its mixing proportions are "
-			    "undefined (the reference carries NaN for it); remove it from the data set or use -c", who);
-	}
 	/* the element-per-thread kernels over parameters take one work-item per entry of P or Q */
 	if ((size_t)K * ctx->T >= ((size_t)1 << 31) || (size_t)K * ctx->I >= ((size_t)1 << 31))
 		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "K*T or K*I of 2^31 or more is not supported%s", nullptr);
@@ -1937,6 +1934,7 @@ int mchip_set_q(mchip_context *ctx, int slot, const double *q)
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(ctx->d_q[slot], q, (size_t)ctx->nq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
+	ctx->empty_rows_nan = 0;
 	return MCHIP_OK;
 }
 
@@ -1948,7 +1946,20 @@ int mchip_get_q(mchip_context *ctx, int slot, double *q)
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(q, ctx->d_q[slot], (size_t)ctx->nq * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
+	/* An individual without a single observed copy: the reference's M step gives it 0 / 0 (em_alg.c:685-690; printed "-nan") and the
+	 * row then sits in its arrays untouched by anything else, every zero-count cell being skipped.  The device keeps a finite row
+	 * for it (k_finalize_q: 1 / K) so that nothing it is multiplied into turns NaN, and it is reported here as the reference has it */
+	if (ctx->qstride && ctx->empty_rows_nan)
+		for (int i : ctx->empty_rows)
+			for (int k = 0; k < ctx->K; k++) q[(size_t)i * ctx->K + k] = -__builtin_nan("");
 	return MCHIP_OK;
+}
+
+int mchip_empty_individuals(const mchip_context *ctx, int *first)
+{
+	if (!ctx) return 0;
+	if (first) *first = ctx->first_empty;
+	return (int)ctx->empty_rows.size();
 }
 
 static int fetch_scalars(mchip_context *ctx, int first, int count, double *out)
@@ -2043,6 +2054,7 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 		ctx->kt->finalize_q(ctx->I, ctx->K, 1, ctx->d_ssum, ctx->d_q[from], ctx->qstride,
 				    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream, 0.0);
 	}
+	if (do_mstep && indiv) ctx->empty_rows_nan = 1;
 	if (do_mstep) {
 		if (!indiv) {
 			int rc = finalize_shared_eta(ctx, to, stop);
@@ -2072,6 +2084,7 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	if (!state || n_steps < 1) return fail(ctx, MCHIP_ERR_INVALID, "em_run: bad arguments%s", nullptr);
+	if (ctx->qstride) ctx->empty_rows_nan = 1;	/* (set here too: a replayed graph does not pass through the enqueueing code) */
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(ctx->d_run, state, sizeof *state, hipMemcpyHostToDevice, ctx->stream));
 	const int *stop = &ctx->d_run->stopped;
@@ -2113,6 +2126,7 @@ int mchip_em_step(mchip_context *ctx, int from, int to, double *loglik)
 	if ((rc = check_slot(ctx, to))) return rc;
 	HIPCHK(hipSetDevice(ctx->device));
 	if ((rc = run_estep(ctx, from, to, 1))) return rc;
+	if (ctx->qstride) ctx->empty_rows_nan = 1;
 	if (loglik) return fetch_scalars(ctx, 0, 1, loglik);
 	return MCHIP_OK;
 }
@@ -2180,6 +2194,7 @@ static int partition_finalize(mchip_context *ctx, int to, int counts, int n_asla
 	const int indiv = ctx->qstride != 0;
 	const int project = counts ? 0 : ctx->do_projection;
 	const double add = counts ? 1.0 : 0.0;
+	ctx->empty_rows_nan = 0;	/* initialize_parameters_admixture starts every count at 1 (rnd_init.c:624): 1 / K for such a row */
 	ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[to], ctx->qstride,
 			    ctx->d_q[to], ctx->d_sik, indiv, 0, project, ctx->eta_lb, nullptr, ctx->stream, add);
 	if (!indiv && (rc = finalize_shared_eta(ctx, to, nullptr, add, !counts))) return rc;
@@ -2507,6 +2522,7 @@ int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const
 	int rc = set_shape(ctx, I, L, ploidy, ua, 1);
 	if (rc) return rc;
 	ctx->first_empty = -1;		/* every copy of a generated data set is drawn */
+	ctx->empty_rows.clear();
 	const size_t n_copies = (size_t)I * L * ploidy;
 	rng_window base;
 	size_t n_chunks, n_blocks;
@@ -2782,6 +2798,7 @@ int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchi
 	if (!state || n_cycles < 1 || scheme < 1 || scheme > 4) return fail(ctx, MCHIP_ERR_INVALID, "accel_run: bad arguments%s", nullptr);
 	if ((ctx->admixture && !ctx->sparse) || ctx->nsec < 1)
 		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "accel_run: needs a secant pair; loci with more than 32 alleles run cycle by cycle%s", nullptr);
+	if (ctx->qstride) ctx->empty_rows_nan = 1;
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(ctx->d_run, state, sizeof *state, hipMemcpyHostToDevice, ctx->stream));
 	/* does Spart hold the S-side sums of this very slot (mchip_loglik_prefetch, or the accepted cycle that ended the

@@ -1234,6 +1234,13 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_q(int I, int n_lchunks
 		s[k] += add;		/* 0, or the 1 every count of initialize_parameters_admixture starts from (rnd_init.c:624) */
 		temp += s[k];
 	}
+	if (temp == 0.0) {
+		/* no observed copy at all: 0 / 0 in the reference.  A finite row is kept here (mchip_get_q reports it as the reference has
+		 * it); everything this individual's row is multiplied into carries a zero count */
+#pragma unroll
+		for (int k = 0; k < K; k++) Qto[(size_t)i * K + k] = 1.0 / K;
+		return;
+	}
 #pragma unroll
 	for (int k = 0; k < K; k++) s[k] /= temp;
 	if (do_projection) michelot_k(s, lb);

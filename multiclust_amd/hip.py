@@ -66,6 +66,7 @@ def load():
         "mchip_mstep_from_rand_partition": ([vp, vp, i32], i32),
         "mchip_get_genotypes": ([vp, vp], i32),
         "mchip_data_counts": ([vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], i32),
+        "mchip_empty_individuals": ([vp, C.POINTER(C.c_int)], i32),
         "mchip_copy_genotypes": ([vp, vp], i32),
         "mchip_simulate_genotypes": ([vp, i32, i32, i32, vp, vp, i32, i32, vp, vp], i32),
         "mchip_set_init_genotypes": ([vp, vp], i32),
@@ -103,7 +104,7 @@ ABI_SYMBOLS = [
     "mchip_synchronize", "mchip_set_genotypes", "mchip_set_model", "mchip_set_p", "mchip_get_p", "mchip_set_q",
     "mchip_get_q", "mchip_q_length", "mchip_p_length", "mchip_em_step", "mchip_em_run", "mchip_accel_run", "mchip_last_loglik", "mchip_e_step",
     "mchip_loglik", "mchip_loglik_prefetch", "mchip_mstep_from_partition", "mchip_mstep_from_rand_partition",
-    "mchip_get_genotypes", "mchip_data_counts", "mchip_copy_genotypes", "mchip_simulate_genotypes", "mchip_set_init_genotypes",
+    "mchip_get_genotypes", "mchip_data_counts", "mchip_empty_individuals", "mchip_copy_genotypes", "mchip_simulate_genotypes", "mchip_set_init_genotypes",
     "mchip_get_expected_counts", "mchip_init_from_allele_centers", "mchip_copy_slot", "mchip_secant", "mchip_set_secant", "mchip_get_secant", "mchip_step_dots",
     "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
     "mchip_profile_end", "mchip_device_info", "mchip_comm_create", "mchip_comm_all_reduce", "mchip_comm_destroy",

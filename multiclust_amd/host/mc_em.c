@@ -434,11 +434,22 @@ int mc_em_2_steps(mc_model *mod, const mc_data *dat, const mc_options *opt)
 	return 0;
 }
 
+/* An individual without a single observed allele copy has mixing proportions 0 / 0 = NaN in the reference from its first M step
+ * on (em_alg.c:685-690).  Its secants are NaN, so step_size() is NaN and accelerated_em_step() takes its "invalid step size:
+ * fall back on EM step" exit every cycle (accel_em.c:58-62); with q > 1 qn_accelerated_update() moves to a NaN point whose log
+ * likelihood is NaN and refused (accel_em.c:97).  The device holds a finite row for such an individual (mchip_get_q reports it
+ * as NaN), so the NaN has to be supplied here. */
+static int carries_nan_rows(const mc_options *opt, mc_model *mod)
+{
+	return opt->admixture && !opt->eta_constrained && mchip_empty_individuals(mod->dev, NULL) > 0;
+}
+
 double mc_step_size(const mc_options *opt, const mc_data *dat, mc_model *mod)
 {
 	/* accel_em.c:130-243 */
 	double d[3] = { NAN, NAN, NAN }, s;
 	(void)dat;
+	if (carries_nan_rows(opt, mod)) return NAN;	/* u'u, u'(v-u), (v-u)'(v-u) all hold NaN terms in the reference: "invalid step size" */
 	if (dev_fail(mod, mchip_step_dots(mod->dev, mod->delta_index, d), "mc_step_size")) return NAN;
 	const double utu = d[0], utvu = d[1], vutvu = d[2];
 	if (opt->accel_scheme == MC_SQS1) s = utu / utvu;
@@ -478,6 +489,7 @@ double mc_qn_accelerated_update(const mc_options *opt, const mc_data *dat, mc_mo
 	int v_index[9];
 	double ca[9], cb[9], det, d2[2];
 	double *A = mod->A, *Ainv = mod->Ainv;
+	if (carries_nan_rows(opt, mod)) return NAN;
 
 	q1 = mod->delta_index;
 	j = 0;
@@ -627,6 +639,7 @@ static int em_batched(const mc_options *opt, mc_model *mod)
 static int em_accel_batched(const mc_options *opt, mc_model *mod)
 {
 	const int scheme = opt->accel_scheme;		/* 1..3 SQUAREM, 4 = QN with q = 1 */
+	if (carries_nan_rows(opt, mod)) return -1;	/* every cycle falls back to its EM iterate: the host loop does that */
 	while (!mod->stopped) {
 		mchip_run_state st;
 		memset(&st, 0, sizeof st);
