@@ -10,6 +10,7 @@ int mchip_destroy(mchip_context *c){(void)c;return 0;}
 int mchip_init_from_allele_centers(mchip_context *c,const uint8_t*a,const uint64_t*b,const uint32_t*w,uint64_t n,int t){(void)c;(void)a;(void)b;(void)w;(void)n;(void)t;return 2;}
 int mchip_copy_slot(mchip_context *c,int a,int b){(void)c;(void)a;(void)b;return 2;}
 int mchip_copy_genotypes(mchip_context *c,const mchip_context *s){(void)c;(void)s;return 2;}
+int mchip_empty_individuals(const mchip_context *c,int *f){(void)c;if(f)*f=-1;return 0;}
 const char *mchip_last_error(const mchip_context *c){(void)c;return "";}
 int mchip_set_genotypes(mchip_context *c,int a,int b,int d,const int32_t*u,const uint8_t*g){(void)c;(void)a;(void)b;(void)d;(void)u;(void)g;return 2;}
 int mchip_set_model(mchip_context *c,int a,int b,int d,int e,double f,double g,int h){(void)c;(void)a;(void)b;(void)d;(void)e;(void)f;(void)g;(void)h;return 2;}
