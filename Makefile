@@ -25,11 +25,11 @@ $(OBJ)/mchip_k%.o: multiclust_amd/csrc/mchip_kernels_k.hip multiclust_amd/csrc/m
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -DMCHIP_K=$* -c $< -o $@
 
-$(OBJ)/mchip.o: multiclust_amd/csrc/mchip.hip multiclust_amd/csrc/mchip_internal.h include/multiclust_hip.h
+$(OBJ)/mchip.o: multiclust_amd/csrc/mchip.hip multiclust_amd/csrc/mchip_internal.h multiclust_amd/csrc/mchip_progress.h include/multiclust_hip.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -c $< -o $@
 
-$(OBJ)/mchip_comm.o: multiclust_amd/csrc/mchip_comm.hip include/multiclust_hip.h
+$(OBJ)/mchip_comm.o: multiclust_amd/csrc/mchip_comm.hip multiclust_amd/csrc/mchip_progress.h include/multiclust_hip.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -c $< -o $@
 

@@ -374,6 +374,9 @@ def attach_cpu_baseline(out, *a, **kw):
         sys.stderr.write("bench.py: cpu_baseline failed: %s: %s\n" % (type(e).__name__, e))
         out["cpu_baseline"] = {"value": None, "unit": "EM iterations/s", "cores": 0, "kind": "port", "sample": None,
                                "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    # a line whose CPU figure is not the reference's own em() (binary absent, its run failed, or the whole leg failed) says so at
+    # the top level, where a reader of the line -- or a check of it -- cannot miss it
+    out["cpu_baseline_degraded"] = out["cpu_baseline"].get("kind") != "reference"
 
 
 def gpu_over_cpu(out):
@@ -818,7 +821,7 @@ def finish(env, args, out, scaling):
     # (nccl = RCCL), the collectives issued on it and the data-set checksum every rank agreed on before the timed region
     line["exchange"] = {"backend": env.backend if env.dist is not None else "none", "collectives": env.collectives,
                         "data_crc32_all_ranks": WORKLOADS[args.workload].get("data_crc32")}
-    for k in ("roofline", "cpu_baseline", "stability", "secondary"):
+    for k in ("roofline", "cpu_baseline", "cpu_baseline_degraded", "stability", "secondary"):
         if k in out:
             line[k] = out[k]
     emit(json.dumps(line))

@@ -269,6 +269,19 @@ int mchip_profile_end(mchip_context *ctx, double *total_ms, double *kernel_ms, i
 /* device properties the bench reports (name, CU count, memory) */
 int mchip_device_info(mchip_context *ctx, char *name, int name_len, int *compute_units, double *hbm_bytes);
 
+/* ---- where the process stands: the record a watchdog reads when a run makes no progress ----
+ * The reference is one thread of plain C that blocks on nothing but its own loops (em_alg.c:78-88, log_likelihood.c:212-221);
+ * this library blocks on the HIP runtime (stream synchronisation behind every entry point that returns a value, copies,
+ * allocation, graph capture, teardown).  Every entry point and every such runtime call records itself while it runs, and each of
+ * those moments counts one event.  mchip_progress_report writes one line per host thread that has used the library -- the entry
+ * point it is in, the runtime call it waits in (with source line), the last phase the host named, seconds since its last event
+ * -- into buf (any length; truncated, NUL-terminated) and the process-wide event count into *events; either may be NULL / 0.
+ * mchip_progress_note names a phase of the caller's own (a static string: the reader, the writers) and counts as an event.
+ * multiclust's opt-in watchdog (MC_WATCHDOG_S=<seconds>, host/mc_fit.c) polls the count and, when it stands still for that long,
+ * prints the report and leaves with _exit(3). */
+int mchip_progress_report(char *buf, int buf_len, unsigned long long *events);
+int mchip_progress_note(const char *what);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,11 +4,31 @@
  * fails with MCHIP_ERR_NO_DEVICE / MCHIP_ERR_HIP when the GPU path cannot run.
  */
 #include "mchip_internal.h"
+#include "mchip_progress.h"
 
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+/* ------------------------------------------------------------------ progress record (mchip_progress.h) */
+mchip_progress_slot mchip_progress_slots[MCHIP_PROGRESS_SLOTS];
+std::atomic<unsigned long long> mchip_progress_events{0};
+static std::atomic<int> progress_next_slot{0};
+
+mchip_progress_slot *mchip_progress_my_slot(void)
+{
+	static thread_local mchip_progress_slot *mine = nullptr;
+	if (!mine) {
+		int x = progress_next_slot.fetch_add(1, std::memory_order_relaxed);
+		if (x >= MCHIP_PROGRESS_SLOTS) x = MCHIP_PROGRESS_SLOTS - 1;	/* more threads than slots: the last one is shared */
+		mine = &mchip_progress_slots[x];
+		mine->tid.store((long)syscall(SYS_gettid), std::memory_order_relaxed);
+	}
+	return mine;
+}
 
 /* ------------------------------------------------------------------ per-K tables */
 #define DECL_KT(n) const mchip_ktable *mchip_ktable_get_##n();
@@ -117,7 +137,7 @@ static int fail(mchip_context *ctx, int code, const char *fmt, const char *detai
 
 #define HIPCHK(call)                                                                                  \
 	do {                                                                                          \
-		hipError_t e_ = (call);                                                               \
+		hipError_t e_ = MCHIP_WAIT(call);                                                     \
 		if (e_ != hipSuccess) {                                                               \
 			snprintf(ctx->err, sizeof ctx->err, "%s failed: %s (%s:%d)", #call,           \
 				 hipGetErrorString(e_), __FILE__, __LINE__);                          \
@@ -127,7 +147,7 @@ static int fail(mchip_context *ctx, int code, const char *fmt, const char *detai
 
 template <typename Tp> static void dfree(Tp *&p)
 {
-	if (p) (void)hipFree(p);
+	if (p) (void)MCHIP_WAIT(hipFree(p));
 	p = nullptr;
 }
 
@@ -137,7 +157,7 @@ template <typename Tp> struct scoped_dev {
 	scoped_dev() = default;
 	scoped_dev(const scoped_dev &) = delete;
 	scoped_dev &operator=(const scoped_dev &) = delete;
-	~scoped_dev() { if (p) (void)hipFree(p); }
+	~scoped_dev() { if (p) (void)MCHIP_WAIT(hipFree(p)); }
 	hipError_t alloc(size_t count) { return hipMalloc((void **)&p, count * sizeof(Tp)); }
 	operator Tp *() const { return p; }
 };
@@ -1326,10 +1346,10 @@ static void prof_mark(mchip_context *ctx, int kind, bool start)
 static void drop_graphs(mchip_context *ctx)
 {
 	for (int s = 0; s < 3; s++)
-		if (ctx->step_graph[s]) { (void)hipGraphExecDestroy(ctx->step_graph[s]); ctx->step_graph[s] = nullptr; }
+		if (ctx->step_graph[s]) { (void)MCHIP_WAIT(hipGraphExecDestroy(ctx->step_graph[s])); ctx->step_graph[s] = nullptr; }
 	for (int s = 0; s < 3; s++)
 		for (int m = 0; m < 5; m++)
-			if (ctx->cycle_graph[s][m]) { (void)hipGraphExecDestroy(ctx->cycle_graph[s][m]); ctx->cycle_graph[s][m] = nullptr; }
+			if (ctx->cycle_graph[s][m]) { (void)MCHIP_WAIT(hipGraphExecDestroy(ctx->cycle_graph[s][m])); ctx->cycle_graph[s][m] = nullptr; }
 }
 
 static void free_model(mchip_context *ctx)
@@ -1392,35 +1412,37 @@ int mchip_abi_version(void) { return MCHIP_ABI_VERSION; }
 
 int mchip_device_count(int *count)
 {
+	MCHIP_ENTRY();
 	if (!count) return MCHIP_ERR_INVALID;
 	int n = 0;
-	if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+	if (MCHIP_WAIT(hipGetDeviceCount(&n)) != hipSuccess) n = 0;
 	*count = n;
 	return MCHIP_OK;
 }
 
 int mchip_create(mchip_context **out, int device)
 {
+	MCHIP_ENTRY();
 	if (!out) return MCHIP_ERR_INVALID;
 	*out = nullptr;
 	int n = 0;
-	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MCHIP_ERR_NO_DEVICE;
+	if (MCHIP_WAIT(hipGetDeviceCount(&n)) != hipSuccess || n <= 0) return MCHIP_ERR_NO_DEVICE;	/* a process's first runtime call: hipInit */
 	if (device < 0 || device >= n) return MCHIP_ERR_INVALID;
 	mchip_context *ctx = new mchip_context();
 	ctx->first_empty = -1;
 	ctx->device = device;
 	ctx->err[0] = 0;
-	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+	if (MCHIP_WAIT(hipSetDevice(device)) != hipSuccess || MCHIP_WAIT(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
 		delete ctx;
 		return MCHIP_ERR_HIP;
 	}
 	hipDeviceProp_t prop;
-	ctx->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
-	if (hipHostMalloc((void **)&ctx->h_pinned, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-	    hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(double)) != hipSuccess ||
-	    hipMalloc((void **)&ctx->d_run, sizeof(mchip_run_state)) != hipSuccess ||
-	    hipMalloc((void **)&ctx->d_cyc, 4 * sizeof(int)) != hipSuccess ||
-	    hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
+	ctx->n_cu = (MCHIP_WAIT(hipGetDeviceProperties(&prop, device)) == hipSuccess) ? prop.multiProcessorCount : 256;
+	if (MCHIP_WAIT(hipHostMalloc((void **)&ctx->h_pinned, 64 * sizeof(double), hipHostMallocDefault)) != hipSuccess ||
+	    MCHIP_WAIT(hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(double))) != hipSuccess ||
+	    MCHIP_WAIT(hipMalloc((void **)&ctx->d_run, sizeof(mchip_run_state))) != hipSuccess ||
+	    MCHIP_WAIT(hipMalloc((void **)&ctx->d_cyc, 4 * sizeof(int))) != hipSuccess ||
+	    MCHIP_WAIT(hipEventCreate(&ctx->ev_begin)) != hipSuccess || MCHIP_WAIT(hipEventCreate(&ctx->ev_end)) != hipSuccess) {
 		delete ctx;
 		return MCHIP_ERR_ALLOC;
 	}
@@ -1430,19 +1452,20 @@ int mchip_create(mchip_context **out, int device)
 
 int mchip_destroy(mchip_context *ctx)
 {
+	MCHIP_ENTRY();
 	if (!ctx) return MCHIP_OK;
-	(void)hipSetDevice(ctx->device);
-	(void)hipStreamSynchronize(ctx->stream);
+	(void)MCHIP_WAIT(hipSetDevice(ctx->device));
+	(void)MCHIP_WAIT(hipStreamSynchronize(ctx->stream));
 	free_model(ctx);
 	free_data(ctx);
 	dfree(ctx->d_scalars);
 	dfree(ctx->d_cyc);
 	dfree(ctx->d_run);
-	if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
-	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-	(void)hipEventDestroy(ctx->ev_begin);
-	(void)hipEventDestroy(ctx->ev_end);
-	(void)hipStreamDestroy(ctx->stream);
+	if (ctx->h_pinned) (void)MCHIP_WAIT(hipHostFree(ctx->h_pinned));
+	for (hipEvent_t e : ctx->ev_pool) (void)MCHIP_WAIT(hipEventDestroy(e));
+	(void)MCHIP_WAIT(hipEventDestroy(ctx->ev_begin));
+	(void)MCHIP_WAIT(hipEventDestroy(ctx->ev_end));
+	(void)MCHIP_WAIT(hipStreamDestroy(ctx->stream));
 	delete ctx;
 	return MCHIP_OK;
 }
@@ -1451,6 +1474,7 @@ const char *mchip_last_error(const mchip_context *ctx) { return ctx ? ctx->err :
 
 int mchip_synchronize(mchip_context *ctx)
 {
+	MCHIP_ENTRY();
 	if (!ctx) return MCHIP_ERR_INVALID;
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	return MCHIP_OK;
@@ -1458,6 +1482,7 @@ int mchip_synchronize(mchip_context *ctx)
 
 int mchip_device_info(mchip_context *ctx, char *name, int name_len, int *compute_units, double *hbm_bytes)
 {
+	MCHIP_ENTRY();
 	if (!ctx) return MCHIP_ERR_INVALID;
 	hipDeviceProp_t prop;
 	HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
@@ -1596,6 +1621,7 @@ static int install_raw(mchip_context *ctx, const uint8_t *d_raw)
 
 int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, const uint8_t *geno)
 {
+	MCHIP_ENTRY();
 	if (!ctx) return MCHIP_ERR_INVALID;
 	if (!geno) return fail(ctx, MCHIP_ERR_INVALID, "set_genotypes: bad shape or null pointer%s", nullptr);
 	int rc = set_shape(ctx, I, L, ploidy, ua);
@@ -1619,6 +1645,7 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 
 int mchip_copy_genotypes(mchip_context *ctx, const mchip_context *src)
 {
+	MCHIP_ENTRY();
 	if (!ctx || !src || ctx == src) return MCHIP_ERR_INVALID;
 	if (!src->T) return fail(ctx, MCHIP_ERR_STATE, "copy_genotypes: the source holds no data set%s", nullptr);
 	if (src->device != ctx->device) return fail(ctx, MCHIP_ERR_UNSUPPORTED, "copy_genotypes: contexts on different devices%s", nullptr);
@@ -1648,6 +1675,7 @@ int mchip_copy_genotypes(mchip_context *ctx, const mchip_context *src)
 
 int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
 {
+	MCHIP_ENTRY();
 	if (!ctx) return MCHIP_ERR_INVALID;
 	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "no genotypes set%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
@@ -1684,6 +1712,7 @@ int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno)
 
 int mchip_data_counts(mchip_context *ctx, uint64_t *nonempty_cells, uint64_t *allele_copies)
 {
+	MCHIP_ENTRY();
 	if (!ctx) return MCHIP_ERR_INVALID;
 	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "no genotypes set%s", nullptr);
 	if (!ctx->counts_valid) {	/* integer sums: order does not matter */
@@ -1707,6 +1736,7 @@ int mchip_data_counts(mchip_context *ctx, uint64_t *nonempty_cells, uint64_t *al
 
 int mchip_get_genotypes(mchip_context *ctx, uint8_t *geno)
 {
+	MCHIP_ENTRY();
 	if (!ctx || !geno) return MCHIP_ERR_INVALID;
 	if (!ctx->T) return fail(ctx, MCHIP_ERR_STATE, "no genotypes set%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
@@ -1726,6 +1756,7 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constrained, int do_projection,
 		    double eta_lb, double p_lb, int n_secants)
 {
+	MCHIP_ENTRY();
 	if (!ctx) return MCHIP_ERR_INVALID;
 	const int rc = set_model_impl(ctx, K, admixture, eta_constrained, do_projection, eta_lb, p_lb, n_secants);
 	if (rc == MCHIP_ERR_HIP || rc == MCHIP_ERR_ALLOC) free_model(ctx);	/* an allocation that failed half way leaves no model, not a partial one */
@@ -1885,12 +1916,14 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 
 int mchip_q_length(const mchip_context *ctx, int *n)
 {
+	MCHIP_ENTRY();
 	if (!ctx || !n || !ctx->K) return MCHIP_ERR_STATE;
 	*n = ctx->nq;
 	return MCHIP_OK;
 }
 int mchip_p_length(const mchip_context *ctx, int *n)
 {
+	MCHIP_ENTRY();
 	if (!ctx || !n || !ctx->K) return MCHIP_ERR_STATE;
 	*n = ctx->K * ctx->T;
 	return MCHIP_OK;
@@ -1898,6 +1931,7 @@ int mchip_p_length(const mchip_context *ctx, int *n)
 
 int mchip_set_p(mchip_context *ctx, int slot, const double *p)
 {
+	MCHIP_ENTRY();
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	ctx->s_cache_slot = -1;
@@ -1913,6 +1947,7 @@ int mchip_set_p(mchip_context *ctx, int slot, const double *p)
 
 int mchip_get_p(mchip_context *ctx, int slot, double *p)
 {
+	MCHIP_ENTRY();
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	if (!p) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
@@ -1927,6 +1962,7 @@ int mchip_get_p(mchip_context *ctx, int slot, double *p)
 
 int mchip_set_q(mchip_context *ctx, int slot, const double *q)
 {
+	MCHIP_ENTRY();
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	ctx->s_cache_slot = -1;
@@ -1940,6 +1976,7 @@ int mchip_set_q(mchip_context *ctx, int slot, const double *q)
 
 int mchip_get_q(mchip_context *ctx, int slot, double *q)
 {
+	MCHIP_ENTRY();
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	if (!q) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
@@ -1957,6 +1994,7 @@ int mchip_get_q(mchip_context *ctx, int slot, double *q)
 
 int mchip_empty_individuals(const mchip_context *ctx, int *first)
 {
+	MCHIP_ENTRY();
 	if (!ctx) return 0;
 	if (first) *first = ctx->first_empty;
 	return (int)ctx->empty_rows.size();
@@ -2081,6 +2119,7 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 
 int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *state)
 {
+	MCHIP_ENTRY();
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	if (!state || n_steps < 1) return fail(ctx, MCHIP_ERR_INVALID, "em_run: bad arguments%s", nullptr);
@@ -2094,13 +2133,13 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
 	bool use_graph = !ctx->profiling && n_steps >= 4 && !getenv("MCHIP_NO_GRAPH");
 	if (use_graph && !ctx->step_graph[slot]) {
 		hipGraph_t graph = nullptr;
-		if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+		if (MCHIP_WAIT(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal)) == hipSuccess) {
 			rc = run_estep(ctx, slot, slot, 1, stop, nullptr, true);
 			hipLaunchKernelGGL(k_stop_check, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_run, ctx->d_scalars, ctx->d_llpart, ctx->ll_parts);
-			const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-			if (rc || e != hipSuccess || !graph || hipGraphInstantiate(&ctx->step_graph[slot], graph, nullptr, nullptr, 0) != hipSuccess)
+			const hipError_t e = MCHIP_WAIT(hipStreamEndCapture(ctx->stream, &graph));
+			if (rc || e != hipSuccess || !graph || MCHIP_WAIT(hipGraphInstantiate(&ctx->step_graph[slot], graph, nullptr, nullptr, 0)) != hipSuccess)
 				ctx->step_graph[slot] = nullptr;
-			if (graph) (void)hipGraphDestroy(graph);
+			if (graph) (void)MCHIP_WAIT(hipGraphDestroy(graph));
 			(void)hipGetLastError();
 		}
 		if (!ctx->step_graph[slot]) use_graph = false;	/* capture unavailable: eager path below */
@@ -2121,6 +2160,7 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
 
 int mchip_em_step(mchip_context *ctx, int from, int to, double *loglik)
 {
+	MCHIP_ENTRY();
 	int rc = check_slot(ctx, from);
 	if (rc) return rc;
 	if ((rc = check_slot(ctx, to))) return rc;
@@ -2133,6 +2173,7 @@ int mchip_em_step(mchip_context *ctx, int from, int to, double *loglik)
 
 int mchip_last_loglik(mchip_context *ctx, double *loglik)
 {
+	MCHIP_ENTRY();
 	if (!ctx || !loglik) return MCHIP_ERR_INVALID;
 	if (!ctx->have_ll) return fail(ctx, MCHIP_ERR_STATE, "no log likelihood computed yet%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
@@ -2141,6 +2182,7 @@ int mchip_last_loglik(mchip_context *ctx, double *loglik)
 
 int mchip_e_step(mchip_context *ctx, int slot, double *loglik)
 {
+	MCHIP_ENTRY();
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(ctx->device));
@@ -2151,6 +2193,7 @@ int mchip_e_step(mchip_context *ctx, int slot, double *loglik)
 
 int mchip_loglik(mchip_context *ctx, int slot, double *loglik)
 {
+	MCHIP_ENTRY();
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(ctx->device));
@@ -2172,6 +2215,7 @@ int mchip_loglik(mchip_context *ctx, int slot, double *loglik)
 
 int mchip_loglik_prefetch(mchip_context *ctx, int slot, double *loglik)
 {
+	MCHIP_ENTRY();
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	if (!ctx->admixture || !ctx->sparse) return mchip_loglik(ctx, slot, loglik);	/* nothing to share on those paths */
@@ -2246,6 +2290,7 @@ static int check_partition_call(mchip_context *ctx, const void *arg, int to)
 
 int mchip_mstep_from_partition(mchip_context *ctx, const uint8_t *assign, int to)
 {
+	MCHIP_ENTRY();
 	int rc = check_partition_call(ctx, assign, to);
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(ctx->device));
@@ -2415,6 +2460,7 @@ static int rand_partition_tiled(mchip_context *ctx, const uint32_t *window, int 
 
 int mchip_mstep_from_rand_partition(mchip_context *ctx, const uint32_t *window, int to)
 {
+	MCHIP_ENTRY();
 	int rc = check_partition_call(ctx, window, to);
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(ctx->device));
@@ -2439,6 +2485,7 @@ int mchip_mstep_from_rand_partition(mchip_context *ctx, const uint32_t *window, 
 int mchip_init_from_allele_centers(mchip_context *ctx, const uint8_t *centers, const uint64_t *draw_offset, const uint32_t *window,
 				   uint64_t n_draws, int to)
 {
+	MCHIP_ENTRY();
 	int rc = check_partition_call(ctx, centers, to);
 	if (rc) return rc;
 	if (!draw_offset || !window) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
@@ -2453,7 +2500,7 @@ int mchip_init_from_allele_centers(mchip_context *ctx, const uint8_t *centers, c
 	size_t n_chunks = 0, n_blocks = 0;
 	auto grow = [&](void **p, size_t *have, size_t want) -> hipError_t {
 		if (*have >= want) return hipSuccess;
-		if (*p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*p); *p = nullptr; *have = 0; }
+		if (*p) { (void)MCHIP_WAIT(hipStreamSynchronize(ctx->stream)); (void)MCHIP_WAIT(hipFree(*p)); *p = nullptr; *have = 0; }
 		const hipError_t e = hipMalloc(p, want);
 		if (e == hipSuccess) *have = want;
 		return e;
@@ -2496,12 +2543,13 @@ int mchip_init_from_allele_centers(mchip_context *ctx, const uint8_t *centers, c
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	if (bad) return fail(ctx, MCHIP_ERR_INVALID, "allele-center draws run past the stream span: offsets do not match the genotype held%s", nullptr);
 	rc = partition_mstep(ctx, d_raw, to, 1);
-	(void)hipStreamSynchronize(ctx->stream);	/* centers / draw_offset are the caller's: uploaded by now */
+	(void)MCHIP_WAIT(hipStreamSynchronize(ctx->stream));	/* centers / draw_offset are the caller's: uploaded by now */
 	return rc;
 }
 
 int mchip_copy_slot(mchip_context *ctx, int to, int from)
 {
+	MCHIP_ENTRY();
 	int rc = check_slot(ctx, to);
 	if (rc || (rc = check_slot(ctx, from))) return rc;
 	if (to == from) return MCHIP_OK;
@@ -2515,6 +2563,7 @@ int mchip_copy_slot(mchip_context *ctx, int to, int from)
 int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int32_t *ua, const uint32_t *window,
 			     int K, int eta_constrained, const double *q, const double *p)
 {
+	MCHIP_ENTRY();
 	if (!ctx) return MCHIP_ERR_INVALID;
 	if (!window || !q || !p || K < 1) return fail(ctx, MCHIP_ERR_INVALID, "simulate_genotypes: null pointer or K < 1%s", nullptr);
 	/* a replicate of the same observed data: the observed haplotypes installed by mchip_set_init_genotypes stay in force
@@ -2562,7 +2611,7 @@ int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const
 		}
 		HIPCHK(hipGetLastError());
 		rc = install_layouts(ctx, 0);
-		(void)hipStreamSynchronize(ctx->stream);	/* the temporaries go out of scope */
+		(void)MCHIP_WAIT(hipStreamSynchronize(ctx->stream));	/* the temporaries go out of scope */
 		return rc;
 	}
 	if ((rc = stream_buffer(ctx))) return rc;	/* n_chunks * RNG_CHUNK / 2 <= its size */
@@ -2577,12 +2626,13 @@ int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const
 				   (uint32_t *)d_raw);
 	HIPCHK(hipGetLastError());
 	rc = install_raw(ctx, d_raw);
-	(void)hipStreamSynchronize(ctx->stream);	/* the temporaries go out of scope */
+	(void)MCHIP_WAIT(hipStreamSynchronize(ctx->stream));	/* the temporaries go out of scope */
 	return rc;
 }
 
 int mchip_get_expected_counts(mchip_context *ctx, double *sik)
 {
+	MCHIP_ENTRY();
 	if (!ctx || !sik) return MCHIP_ERR_INVALID;
 	if (!ctx->K) return fail(ctx, MCHIP_ERR_STATE, "no model set%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
@@ -2604,6 +2654,7 @@ static int check_secant(mchip_context *ctx, int j)
  * the parameter slots' own flat order, so that a quasi-Newton run with q > 1 can be resumed from a recorded state */
 int mchip_set_secant(mchip_context *ctx, int which, int j, const double *p_part, const double *q_part)
 {
+	MCHIP_ENTRY();
 	int rc = check_secant(ctx, j);
 	if (rc) return rc;
 	if (!p_part || !q_part || (which != 0 && which != 1)) return fail(ctx, MCHIP_ERR_INVALID, "set_secant: bad arguments%s", nullptr);
@@ -2618,6 +2669,7 @@ int mchip_set_secant(mchip_context *ctx, int which, int j, const double *p_part,
 }
 int mchip_get_secant(mchip_context *ctx, int which, int j, double *p_part, double *q_part)
 {
+	MCHIP_ENTRY();
 	int rc = check_secant(ctx, j);
 	if (rc) return rc;
 	if (!p_part || !q_part || (which != 0 && which != 1)) return fail(ctx, MCHIP_ERR_INVALID, "get_secant: bad arguments%s", nullptr);
@@ -2633,6 +2685,7 @@ int mchip_get_secant(mchip_context *ctx, int which, int j, double *p_part, doubl
 
 int mchip_secant(mchip_context *ctx, int which, int j, int to, int from)
 {
+	MCHIP_ENTRY();
 	int rc = check_secant(ctx, j);
 	if (rc) return rc;
 	if ((rc = check_slot(ctx, to)) || (rc = check_slot(ctx, from))) return rc;
@@ -2673,6 +2726,7 @@ static int dots_common(mchip_context *ctx, const double *uq, const double *vq, c
 
 int mchip_step_dots(mchip_context *ctx, int j, double *out3)
 {
+	MCHIP_ENTRY();
 	int rc = check_secant(ctx, j);
 	if (rc) return rc;
 	if (!out3) return MCHIP_ERR_INVALID;
@@ -2682,6 +2736,7 @@ int mchip_step_dots(mchip_context *ctx, int j, double *out3)
 
 int mchip_secant_dots(mchip_context *ctx, int j1, int j2, double *out2)
 {
+	MCHIP_ENTRY();
 	int rc = check_secant(ctx, j1);
 	if (rc) return rc;
 	if ((rc = check_secant(ctx, j2))) return rc;
@@ -2702,6 +2757,7 @@ static int project_slot(mchip_context *ctx, int to, const int *stop = nullptr)
 
 int mchip_accel_update(mchip_context *ctx, int to, int base, int j, double s, int qn_form)
 {
+	MCHIP_ENTRY();
 	int rc = check_secant(ctx, j);
 	if (rc) return rc;
 	ctx->s_cache_slot = -1;
@@ -2793,6 +2849,7 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 
 int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchip_run_state *state)
 {
+	MCHIP_ENTRY();
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	if (!state || n_cycles < 1 || scheme < 1 || scheme > 4) return fail(ctx, MCHIP_ERR_INVALID, "accel_run: bad arguments%s", nullptr);
@@ -2811,11 +2868,11 @@ int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchi
 	hipGraphExec_t &exec = ctx->cycle_graph[slot][scheme];
 	if (use_graph && !exec) {
 		hipGraph_t graph = nullptr;
-		if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+		if (MCHIP_WAIT(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal)) == hipSuccess) {
 			rc = accel_cycle_enqueue(ctx, slot, scheme);
-			const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-			if (rc || e != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
-			if (graph) (void)hipGraphDestroy(graph);
+			const hipError_t e = MCHIP_WAIT(hipStreamEndCapture(ctx->stream, &graph));
+			if (rc || e != hipSuccess || !graph || MCHIP_WAIT(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)) != hipSuccess) exec = nullptr;
+			if (graph) (void)MCHIP_WAIT(hipGraphDestroy(graph));
 			(void)hipGetLastError();
 		}
 		if (!exec) use_graph = false;
@@ -2837,6 +2894,7 @@ int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchi
 int mchip_multisecant_update(mchip_context *ctx, int to, int base, int u_index, int n_terms,
 			     const int *v_index, const double *coef_a, const double *coef_b)
 {
+	MCHIP_ENTRY();
 	int rc = check_secant(ctx, u_index);
 	if (rc) return rc;
 	ctx->s_cache_slot = -1;
@@ -2858,6 +2916,7 @@ int mchip_multisecant_update(mchip_context *ctx, int to, int base, int u_index, 
 /* ---- measurement hooks ---- */
 int mchip_profile_begin(mchip_context *ctx)
 {
+	MCHIP_ENTRY();
 	if (!ctx) return MCHIP_ERR_INVALID;
 	HIPCHK(hipSetDevice(ctx->device));
 	ctx->profiling = 1;
@@ -2869,6 +2928,7 @@ int mchip_profile_begin(mchip_context *ctx)
 
 int mchip_profile_end(mchip_context *ctx, double *total_ms, double *kernel_ms, int *launches)
 {
+	MCHIP_ENTRY();
 	if (!ctx) return MCHIP_ERR_INVALID;
 	if (!ctx->profiling) return fail(ctx, MCHIP_ERR_STATE, "profile_end without profile_begin%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
@@ -2896,6 +2956,38 @@ int mchip_profile_end(mchip_context *ctx, double *total_ms, double *kernel_ms, i
 	for (int x = 0; x < MCHIP_KERN_COUNT; x++) {
 		if (kernel_ms) kernel_ms[x] = km[x];
 		if (launches) launches[x] = kl[x];
+	}
+	return MCHIP_OK;
+}
+
+/* ---- where the process stands (mchip_progress.h) ---- */
+int mchip_progress_note(const char *what)
+{
+	mchip_progress_slot *s = mchip_progress_my_slot();
+	s->note.store(what, std::memory_order_relaxed);
+	s->since_ns.store(mchip_progress_now(), std::memory_order_relaxed);
+	mchip_progress_events.fetch_add(1, std::memory_order_relaxed);
+	return MCHIP_OK;
+}
+
+int mchip_progress_report(char *buf, int buf_len, unsigned long long *events)
+{
+	if (events) *events = mchip_progress_events.load(std::memory_order_relaxed);
+	if (!buf || buf_len <= 0) return MCHIP_OK;
+	int n = progress_next_slot.load(std::memory_order_relaxed), used = 0;
+	if (n > MCHIP_PROGRESS_SLOTS) n = MCHIP_PROGRESS_SLOTS;
+	const long long now = mchip_progress_now();
+	buf[0] = 0;
+	for (int x = 0; x < n && used < buf_len - 1; x++) {
+		const mchip_progress_slot &s = mchip_progress_slots[x];
+		const char *entry = s.entry.load(std::memory_order_relaxed), *wait = s.wait.load(std::memory_order_relaxed);
+		const char *note = s.note.load(std::memory_order_relaxed);
+		const int w = snprintf(buf + used, (size_t)(buf_len - used), "thread %ld: %s%s%s%s%s%s, %.1f s since its last event\n",
+				       s.tid.load(std::memory_order_relaxed), entry ? "in " : "outside the library", entry ? entry : "",
+				       wait ? ", waiting in " : "", wait ? wait : "", note ? "; last phase: " : "", note ? note : "",
+				       1e-9 * (double)(now - s.since_ns.load(std::memory_order_relaxed)));
+		if (w < 0) break;
+		used += w < buf_len - used ? w : buf_len - used - 1;
 	}
 	return MCHIP_OK;
 }

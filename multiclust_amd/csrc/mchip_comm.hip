@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "multiclust_hip.h"
+#include "mchip_progress.h"
 
 struct mchip_comm {
 	int n;
@@ -76,6 +77,7 @@ const char *mchip_comm_last_error(const mchip_comm *comm) { return comm ? comm->
 
 int mchip_comm_create(mchip_comm **out, int n_devices, const int *devices)
 {
+	MCHIP_ENTRY();
 	if (!out || n_devices < 1 || !devices) return MCHIP_ERR_INVALID;
 	*out = nullptr;
 	int have = 0;
@@ -112,7 +114,7 @@ int mchip_comm_create(mchip_comm **out, int n_devices, const int *devices)
 	fflush(stdout);
 	const int saved = dup(1), devnull = open("/dev/null", O_WRONLY);
 	if (saved >= 0 && devnull >= 0) dup2(devnull, 1);
-	ncclResult_t r = c->CommInitAll(c->comms.data(), n_devices, devices);
+	ncclResult_t r = MCHIP_WAIT(c->CommInitAll(c->comms.data(), n_devices, devices));
 	fflush(stdout);
 	if (saved >= 0) { dup2(saved, 1); close(saved); }
 	if (devnull >= 0) close(devnull);
@@ -138,6 +140,7 @@ int mchip_comm_create(mchip_comm **out, int n_devices, const int *devices)
 
 int mchip_comm_all_reduce(mchip_comm *c, double *const *host_bufs, int count, int op)
 {
+	MCHIP_ENTRY();
 	if (!c || !host_bufs || count <= 0 || (op != 0 && op != 1)) return MCHIP_ERR_INVALID;
 	if ((size_t)count > c->cap) {
 		for (int d = 0; d < c->n; d++) {
@@ -155,12 +158,12 @@ int mchip_comm_all_reduce(mchip_comm *c, double *const *host_bufs, int count, in
 	ncclResult_t r = c->GroupStart();
 	for (int d = 0; d < c->n && r == ncclSuccess; d++)
 		r = c->AllReduce(c->dbuf[d], c->dbuf[d], (size_t)count, ncclFloat64, op ? ncclMax : ncclSum, c->comms[d], c->streams[d]);
-	if (r == ncclSuccess) r = c->GroupEnd();
+	if (r == ncclSuccess) r = MCHIP_WAIT(c->GroupEnd());
 	if (r != ncclSuccess) return cfail(c, MCHIP_ERR_HIP, "ncclAllReduce", c->GetErrorString(r));
 	for (int d = 0; d < c->n; d++) {
 		if (hipSetDevice(c->devices[d]) != hipSuccess ||
 		    hipMemcpyAsync(host_bufs[d], c->dbuf[d], sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->streams[d]) != hipSuccess ||
-		    hipStreamSynchronize(c->streams[d]) != hipSuccess)
+		    MCHIP_WAIT(hipStreamSynchronize(c->streams[d])) != hipSuccess)
 			return cfail(c, MCHIP_ERR_HIP, "download", "");
 	}
 	c->n_reductions++;
@@ -182,12 +185,13 @@ int mchip_comm_info(const mchip_comm *c, int *n_devices, int *rccl_version, unsi
 
 int mchip_comm_destroy(mchip_comm *c)
 {
+	MCHIP_ENTRY();
 	if (!c) return MCHIP_OK;
 	for (int d = 0; d < c->n; d++) {
 		(void)hipSetDevice(c->devices[d]);
-		if (c->dbuf[d]) (void)hipFree(c->dbuf[d]);
-		if (d < (int)c->streams.size()) (void)hipStreamDestroy(c->streams[d]);
-		if (d < (int)c->comms.size() && c->comms[d]) (void)c->CommDestroy(c->comms[d]);
+		if (c->dbuf[d]) (void)MCHIP_WAIT(hipFree(c->dbuf[d]));
+		if (d < (int)c->streams.size()) (void)MCHIP_WAIT(hipStreamDestroy(c->streams[d]));
+		if (d < (int)c->comms.size() && c->comms[d]) (void)MCHIP_WAIT(c->CommDestroy(c->comms[d]));
 	}
 	if (c->dl) dlclose(c->dl);
 	delete c;

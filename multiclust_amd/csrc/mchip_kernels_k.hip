@@ -1043,20 +1043,32 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_mix_finalize(int I, int n_lchun
 			ll = log(temp) + mx;
 		} else {
 			double temp_exp = exp(mx), scale_exp = 0.0;
-			if (temp_exp == 0.0 || temp_exp == HUGE_VAL) {
-				scale_exp = (temp_exp == HUGE_VAL) ? mx : -mx;
-				do {
-					scale_exp *= 0.5;
-					temp_exp = exp(scale_exp);
-				} while (temp_exp == HUGE_VAL);
-				scale_exp = mx - scale_exp;
+			/* The reference halves scale_exp until exp() stops overflowing (log_likelihood.c:212-221).  When no v[k] is an
+			 * ordinary number -- every one NaN (a negative extrapolated p with the projection off: log() = NaN in k_logp) or
+			 * -inf, or one +inf -- mx is infinite, scale_exp = inf, inf / 2 = inf, and its loop never ends: on the CPU a
+			 * process that spins, here a wave the stream never gets back from.  Such an individual's term is NaN instead: the
+			 * sum is NaN, and stop() ends the run on "nan" (em_alg.c:106-110), which is where a NaN leads the reference whenever
+			 * its loop does end.  A finite mx needs at most log2(DBL_MAX / 709) < 1 016 halvings (a dozen for any sum of logs a
+			 * data set can produce); the cap states that bound. */
+			if (!(mx > -INFINITY && mx < INFINITY)) {
+				ll = __builtin_nan("");
+			} else {
+				if (temp_exp == 0.0 || temp_exp == HUGE_VAL) {
+					scale_exp = (temp_exp == HUGE_VAL) ? mx : -mx;
+					int halvings = 0;
+					do {
+						scale_exp *= 0.5;
+						temp_exp = exp(scale_exp);
+					} while (temp_exp == HUGE_VAL && ++halvings < 2048);
+					scale_exp = mx - scale_exp;
 #pragma unroll
-				for (int k = 0; k < K; k++) v[k] -= scale_exp;
+					for (int k = 0; k < K; k++) v[k] -= scale_exp;
+				}
+				temp_exp = 0.0;
+#pragma unroll
+				for (int k = 0; k < K; k++) temp_exp = temp_exp + exp(v[k]);
+				ll = log(temp_exp) + scale_exp;
 			}
-			temp_exp = 0.0;
-#pragma unroll
-			for (int k = 0; k < K; k++) temp_exp = temp_exp + exp(v[k]);
-			ll = log(temp_exp) + scale_exp;
 		}
 	}
 	const double tot = block_sum<MCHIP_BLOCK>(ll, red);

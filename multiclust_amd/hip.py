@@ -88,6 +88,8 @@ def load():
         "mchip_comm_destroy": ([vp], i32),
         "mchip_comm_last_error": ([vp], C.c_char_p),
         "mchip_comm_info": ([vp, ip, ip, C.POINTER(C.c_ulonglong)], i32),
+        "mchip_progress_report": ([C.c_char_p, i32, C.POINTER(C.c_ulonglong)], i32),
+        "mchip_progress_note": ([C.c_char_p], i32),
     }
     for name, (args, res) in sig.items():
         if "MCHIP_LIB_PATH" in os.environ and not hasattr(lib, name):
@@ -108,7 +110,7 @@ ABI_SYMBOLS = [
     "mchip_get_expected_counts", "mchip_init_from_allele_centers", "mchip_copy_slot", "mchip_secant", "mchip_set_secant", "mchip_get_secant", "mchip_step_dots",
     "mchip_secant_dots", "mchip_accel_update", "mchip_multisecant_update", "mchip_profile_begin",
     "mchip_profile_end", "mchip_device_info", "mchip_comm_create", "mchip_comm_all_reduce", "mchip_comm_destroy",
-    "mchip_comm_last_error", "mchip_comm_info",
+    "mchip_comm_last_error", "mchip_comm_info", "mchip_progress_report", "mchip_progress_note",
 ]
 
 

@@ -60,6 +60,50 @@ class McSummary(C.Structure):
                 ("aic", C.c_double), ("bic", C.c_double)]
 
 
+class CliOptions(C.Structure):
+    """mc_cli_options (multiclust_amd/host/mc_cli.h)"""
+    _fields_ = [("em", McOptions), ("filename", C.c_char_p), ("filename_file", C.c_char_p), ("path", C.c_char_p),
+                ("outfile_name", C.c_char_p), ("min_K", C.c_int), ("max_K", C.c_int), ("n_init", C.c_int),
+                ("n_bootstrap", C.c_int), ("n_rand_em_init", C.c_int), ("missing_value", C.c_int), ("R_format", C.c_int),
+                ("ploidy", C.c_int), ("seed_given", C.c_int), ("target_ll", C.c_int), ("target_revisit", C.c_int),
+                ("desired_ll", C.c_double), ("n_repeat", C.c_int), ("repeat_seconds", C.c_uint),
+                ("max_repeat_seconds", C.c_uint), ("write_files", C.c_int), ("compact", C.c_int), ("parallel", C.c_int),
+                ("device", C.c_int), ("n_gpus", C.c_int), ("n_streams", C.c_int), ("pfile", C.c_char_p), ("qfile", C.c_char_p),
+                ("afile", C.c_char_p)]
+
+
+class CliData(C.Structure):
+    """mc_cli_data (multiclust_amd/host/mc_cli.h)"""
+    _fields_ = [("I", C.c_int), ("L", C.c_int), ("ploidy", C.c_int), ("M", C.c_int), ("missing_data", C.c_int),
+                ("interleaved", C.c_int), ("IL", C.POINTER(C.c_int)), ("uniquealleles", C.POINTER(C.c_int32)),
+                ("L_alleles", C.POINTER(C.POINTER(C.c_int))), ("geno", C.POINTER(C.c_uint8)),
+                ("names", C.POINTER(C.c_char_p)), ("locale", C.POINTER(C.c_int)), ("pops", C.POINTER(C.c_char_p)),
+                ("numpops", C.c_int), ("i_p", C.POINTER(C.c_int)), ("T", C.c_int), ("toff", C.POINTER(C.c_int32))]
+
+
+def read_structure(path, ploidy=2, missing=-9, r_format=0):
+    """mc_read_structure (host/mc_reader.c; reference read_file.c:38-300, 443-663) on a STRUCTURE file: (status, None) on
+    failure, else (0, dict of the fields the EM path and the writers read)."""
+    lib = load()
+    lib.mc_read_structure.argtypes = [C.POINTER(CliOptions), C.POINTER(CliData)]
+    lib.mc_free_data.argtypes = [C.POINTER(CliData)]
+    o = CliOptions()
+    o.filename = path.encode()
+    o.ploidy, o.missing_value, o.R_format = ploidy, missing, r_format
+    d = CliData()
+    rc = lib.mc_read_structure(C.byref(o), C.byref(d))
+    if rc:
+        return rc, None
+    out = dict(I=d.I, L=d.L, ploidy=d.ploidy, T=d.T, M=d.M, missing_data=d.missing_data, interleaved=d.interleaved,
+               ua=np.ctypeslib.as_array(d.uniquealleles, shape=(d.L,)).copy(),
+               geno=np.ctypeslib.as_array(d.geno, shape=(d.I, d.L, d.ploidy)).copy(),
+               locale=np.ctypeslib.as_array(d.locale, shape=(d.I,)).copy(), numpops=d.numpops,
+               names=[d.names[i].decode() for i in range(d.I)], pops=[d.pops[i].decode() for i in range(d.numpops)],
+               i_p=[d.i_p[n] for n in range(d.numpops)])
+    lib.mc_free_data(C.byref(d))
+    return 0, out
+
+
 _lib = None
 
 

@@ -43,6 +43,7 @@ typedef struct mc_cli_options {
 	int n_streams;			/* --streams (extension): concurrent fits per device, each with its own context and
 					 * stream; small data sets do not fill a GPU with one fit */
 	const char *pfile, *qfile;	/* -P / -Q: initial parameters of the admixture model from files (read_file.c:880-959) */
+	const char *afile;		/* -A: a partition of the individuals to compare the fitted one with (multiclust.c:1416-1418) */
 } mc_cli_options;
 
 typedef struct mc_cli_data {
@@ -75,6 +76,12 @@ typedef struct mc_fit_view {
 	const double *sik;	/* [I][K]: sum_lm d_iklm of the last E step, or vik */
 } mc_fit_view;
 
+/* read_afile (read_file.c:970-999): I cluster labels 1, 2, ... (white space between them) -> labels[i] - 1 and their number
+ * *pK = largest label; returns 0 or the reference's exit status for the failure (file cannot be opened 5, contents 7) */
+int mc_read_afile(const char *path, int I, int **labels, int *pK);
+/* adj_rand(..., ADJUSTED_RAND_INDEX) (multiclust.c:1903-1985): adjusted Rand index of two labelings of n observations with k1
+ * and k2 classes, the reference's sums in the reference's order; NaN (0 / 0) where it has it */
+double mc_adjusted_rand(int n, int k1, int k2, const int *cl1, const int *cl2);
 /* partition_admixture / partition_mixture (write_file.c:350-382, 585-603): MAP cluster per individual, count_K */
 void mc_partition(const mc_cli_data *dat, const mc_fit_view *fit, int *I_K, int *count_K);
 /* write_file_detail + popq_* + indivq_* (write_file.c:203-348, 398-475, 492-569, 618-732) */

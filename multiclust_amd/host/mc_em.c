@@ -283,6 +283,7 @@ static void draw_partition(uint8_t *assign, size_t n, int K, mc_rng *rng)
 	}
 	draw_job jobs[64];
 	pthread_t th[64];
+	int joinable[64] = { 0 };	/* (a pthread_t has no "none" value) */
 	if (nt > 64) nt = 64;
 	const size_t per = (n + (size_t)nt - 1) / (size_t)nt;
 	for (int t = 0; t < nt; t++) {
@@ -292,9 +293,10 @@ static void draw_partition(uint8_t *assign, size_t n, int K, mc_rng *rng)
 		jobs[t].K = K;
 		jobs[t].rng = *rng;
 		mc_rng_jump(&jobs[t].rng, (uint64_t)lo);
-		if (pthread_create(&th[t], NULL, draw_main, &jobs[t])) { draw_main(&jobs[t]); th[t] = 0; }
+		if (pthread_create(&th[t], NULL, draw_main, &jobs[t])) draw_main(&jobs[t]);	/* no thread to be had: in this one */
+		else joinable[t] = 1;
 	}
-	for (int t = 0; t < nt; t++) if (th[t]) pthread_join(th[t], NULL);
+	for (int t = 0; t < nt; t++) if (joinable[t]) pthread_join(th[t], NULL);
 	mc_rng_jump(rng, (uint64_t)n);		/* the caller's stream ends where the serial loop would */
 }
 

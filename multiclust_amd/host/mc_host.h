@@ -14,6 +14,7 @@
 #define MC_HOST_H
 
 #include <stdint.h>
+#include <stdio.h>
 #include <time.h>
 #include "multiclust_hip.h"
 
@@ -184,6 +185,15 @@ typedef struct mc_replicate_result {
  * (free them with mc_model_free when the replicates are done); NULL: models are created and freed inside the call */
 int mc_fit_replicate(const mc_options *opt, const mc_data *dat, int device, const mc_rng *base, int b, int null_K, int alt_K,
 		     int n_init, int mle_K, const double *mle_q, const double *mle_p, mc_replicate_result *out, mc_model **models);
+
+/* ---- opt-in watchdog (mc_watchdog.c): nothing in the reference corresponds -- it has nothing to wait for ----
+ * mc_watchdog_start(s): a detached thread that polls the library's event count (mchip_progress_report) and, when it has stood
+ * still for s seconds, prints where every thread stands (library record + /proc/self/task) on stderr and leaves with _exit(3).
+ * mc_watchdog_from_env(): the same with s = $MC_WATCHDOG_S, nothing when the variable is unset.  mc_watchdog_report(): the
+ * report alone (used by the tests). */
+int mc_watchdog_start(double seconds);
+int mc_watchdog_from_env(void);
+void mc_watchdog_report(FILE *fp, double quiet_seconds);
 
 #ifdef __cplusplus
 }

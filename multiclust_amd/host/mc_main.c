@@ -7,7 +7,7 @@
  * initialisation loop and bookkeeping of maximize_likelihood (471-656), the per-initialisation stdout line
  * (618-627), print_model_state (718-793), run_bootstrap (675-708) and the -w repetition summary (201-347).
  * Deliberately absent (documented in DESIGN.md): -I/-I1 (allele-index mode gives different numbers from default
- * mode in the reference itself), --impute, --simulate, -x (not implemented in the reference either), -A, -P/-Q.
+ * mode in the reference itself), --impute, --simulate, -x (not implemented in the reference either).
  * Extensions: --device <n> selects the HIP device; --streams <n> runs n fits at a time per GPU; --gpus <n> shards the initialisations of each K over n GPUs of
  * the node (one host thread and one context per GPU, units u = d, d+n, ..., each starting from the serial program's
  * rand() position by jump-ahead), with a single RCCL all-reduce of the per-unit result table, after which the serial
@@ -48,7 +48,8 @@ static void usage(FILE *fp, const char *prog)
 		"  --gpus <n>    shard the initialisations over n GPUs (admixture; one RCCL all-reduce of the results)\n"
 		"  --streams <n> n concurrent fits per GPU, each on its own stream (small data sets do not fill a GPU)\n"
 		"  -P <file> -Q <file>  initial allele frequencies p[k][l][0] (L*K numbers, biallelic loci) and mixing proportions of the admixture model\n"
-		"  --randem      Rand-EM initialisation: the best of -m <n> (50) candidates from random allele centers\n", prog);
+		"  --randem      Rand-EM initialisation: the best of -m <n> (50) candidates from random allele centers\n"
+		"  -A <file>     a partition of the individuals (labels 1, 2, ...): the adjusted Rand index of the fitted one is reported\n", prog);
 }
 
 static int arg_int(int argc, const char **argv, int i, long *out)
@@ -145,7 +146,7 @@ static int parse_options(mc_cli_options *o, int argc, const char **argv)
 			break;
 		case 'P': if (++i >= argc) BAD("-P"); o->pfile = argv[i]; break;
 		case 'Q': if (++i >= argc) BAD("-Q"); o->qfile = argv[i]; break;
-		case 'A': BAD("-A (partition file for the cluster-comparison indices) is not supported by this build");
+		case 'A': if (++i >= argc) BAD("-A"); o->afile = argv[i]; break;	/* multiclust.c:1416-1418 */
 		case 'R': o->R_format = 1; break;
 		case 'r':
 			/* extension: --randem selects the Rand-EM initialisation the reference carries but cannot reach
@@ -214,6 +215,10 @@ typedef struct run_state {
 	mchip_comm **comm;		/* the run's RCCL communicator over devices device..device+n_gpus-1, created on first use */
 	mc_model **sim_models;		/* [2] or NULL: this worker's H0 / HA models of the bootstrap data sets, kept from one replicate to
 					 * the next (same shape, same K: the device re-uses every buffer, mc_model_resimulate) */
+	/* -A (multiclust.c:602-612): the partition read from the file (labels - 1, pK of them), the MAP partition of the last fit that
+	 * was partitioned (dat->I_K) and the adjusted Rand index of the two (model::arand: never reset, as in the reference) */
+	int *partition_from_file, pK, *I_K;
+	double arand;
 } run_state;
 
 /* sharded runs use n_gpus * n_streams workers (host thread + context + stream each); worker x sits on device
@@ -267,7 +272,7 @@ static void print_model_state(const mc_cli_options *o, const mc_cli_data *d, con
 		fprintf(st->out, "%s %s %s %d %u %e %e %e %e %f %f %f ", o->filename, accel_abbrev(o, ab), o->em.admixture ? "admix" : "mix", K,
 		       o->em.seed, o->em.eta_lower_bound, o->em.p_lower_bound, o->em.abs_error, o->em.rel_error,
 		       st->sum.max_logL, st->sum.aic, st->sum.bic);
-		fprintf(st->out, "ND ");
+		if (o->afile) fprintf(st->out, "%f ", st->arand); else fprintf(st->out, "ND ");	/* multiclust.c:728-731 */
 		fprintf(st->out, "%s %02d:%02d:%02d %d %d %d %d", st->sum.ever_converged ? "converged" : "not", diff / 3600, (diff % 3600) / 60,
 		       diff % 60, st->sum.n_total_iter, st->sum.n_init, st->sum.n_maxll_init, st->sum.n_maxll_times);
 		if (o->target_ll) fprintf(st->out, " %f %d %d", o->desired_ll, st->n_targetll_init, st->n_targetll_times);
@@ -343,8 +348,11 @@ static int maximize_likelihood(const mc_cli_options *o, const mc_cli_data *d, co
 		mc_reset_model_state(mod);
 		mod->delta_index = delta_keep;
 		mod->start = start;			/* the time limit spans all initialisations (multiclust.c:488) */
+		mchip_progress_note("maximize_likelihood: initialisation");
 		if ((rc = cli_initialize(o, d, md, mod, &st->rng))) goto DONE;
+		mchip_progress_note("maximize_likelihood: mc_em");
 		mc_em(&o->em, md, mod);
+		mchip_progress_note("maximize_likelihood: bookkeeping and result files");
 		if (mod->fatal == MC_FATAL_DEVICE) { rc = MCHIP_ERR_HIP; goto DONE; }
 		if (mod->fatal) exit(0);		/* the reference's reaction to NaN / decreasing logL (em_alg.c:106-120) */
 		mc_unit_result r = { i, mod->logL, mod->converged, mod->n_iter, mod->time_stop, mod->iter_stop, mod->pindex, 0, mod->seconds_run };
@@ -352,7 +360,8 @@ static int maximize_likelihood(const mc_cli_options *o, const mc_cli_data *d, co
 		mc_summary_add(&o->em, &st->sum, &r, npar, d->I);
 		if (mod->logL > prev_max) {
 			const int keep_mle = !bootstrap && o->n_bootstrap && K == st->null_K;
-			if (keep_mle || (!bootstrap && o->write_files)) {
+			const int part_only = o->afile && !o->write_files;	/* nothing is written, but -A wants the partition */
+			if (keep_mle || (!bootstrap && o->write_files) || part_only) {
 				if (!q) { q = malloc(sizeof(double) * (size_t)nq); p = malloc(sizeof(double) * (size_t)K * d->T);
 					  sik = malloc(sizeof(double) * (size_t)d->I * K); count_K = malloc(sizeof(int) * (size_t)K); }
 				if (!q || !p || !sik || !count_K) { rc = MCHIP_ERR_ALLOC; goto DONE; }
@@ -368,8 +377,20 @@ static int maximize_likelihood(const mc_cli_options *o, const mc_cli_data *d, co
 			}
 			if (!bootstrap && o->write_files) {	/* multiclust.c:584-600 */
 				mc_fit_view fv = { K, mod->converged, mod->logL, st->sum.aic, st->sum.bic, q, p, sik };
-				mc_partition(d, &fv, NULL, count_K);
+				mc_partition(d, &fv, st->I_K, count_K);
 				if ((rc = mc_write_results(o, d, &fv, count_K))) goto DONE;
+			}
+			if (o->afile) {		/* multiclust.c:602-612 */
+				if (part_only) {
+					mc_fit_view fv = { K, mod->converged, mod->logL, st->sum.aic, st->sum.bic, q, p, sik };
+					mc_partition(d, &fv, st->I_K, count_K);
+				}
+				/* (a bootstrap fit with result files on is not partitioned in the reference: dat->I_K is then the partition
+				 * of an earlier fit, possibly with a cluster index this K does not have -- it indexes past its table there;
+				 * the index is left as it was here) */
+				int fits = 1;
+				for (int x = 0; x < d->I; x++) if (st->I_K[x] >= K) fits = 0;
+				if (fits) st->arand = mc_adjusted_rand(d->I, st->pK, K, st->partition_from_file, st->I_K);
 			}
 		}
 		if (!bootstrap && o->em.verbosity > MC_QUIET && o->write_files)	/* multiclust.c:618-627 */
@@ -459,11 +480,12 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 	const double max_logL_keep = st->sum.max_logL, aic_keep = st->sum.aic, bic_keep = st->sum.bic;
 	shard_worker *w = calloc((size_t)n_dev, sizeof *w);
 	pthread_t *th = calloc((size_t)n_dev, sizeof *th);
+	int *joinable = calloc((size_t)n_dev, sizeof *joinable);	/* (a pthread_t has no "none" value) */
 	mc_unit_result *res = calloc((size_t)n_units, sizeof *res);
 	double **tab = calloc((size_t)n_gpus, sizeof *tab);
 	int *count_K = calloc((size_t)K, sizeof *count_K), rc = 0;
 	mc_rng *starts = calloc((size_t)n_units + 1, sizeof *starts);
-	if (!w || !th || !res || !tab || !count_K || !starts) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+	if (!w || !th || !joinable || !res || !tab || !count_K || !starts) { rc = MCHIP_ERR_ALLOC; goto DONE; }
 	{	/* where each unit starts in the rand() stream: one walk (a jump per unit for the random allele partition, the host-side
 		 * replay of the center draws for Rand-EM), instead of every worker replaying the units before its own */
 		mc_model walker;
@@ -475,12 +497,13 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 	}
 	for (int x = 0; x < n_dev; x++) {
 		w[x].o = o; w[x].d = d; w[x].md = md; w[x].K = K; w[x].index = x; w[x].n_dev = n_dev; w[x].n_units = n_units;
-		w[x].want_params = keep_mle || (!bootstrap && o->write_files);
+		w[x].want_params = keep_mle || (!bootstrap && o->write_files) || o->afile != NULL;
 		w[x].sim = sim;
 		w[x].starts = starts; w[x].draws = mc_draws_per_init(&o->em, md, K); w[x].res = res;
-		if (pthread_create(&th[x], NULL, shard_main, &w[x])) { shard_main(&w[x]); th[x] = 0; }
+		if (pthread_create(&th[x], NULL, shard_main, &w[x])) shard_main(&w[x]);	/* no thread to be had: in this one */
+		else joinable[x] = 1;
 	}
-	for (int x = 0; x < n_dev; x++) if (th[x]) pthread_join(th[x], NULL);
+	for (int x = 0; x < n_dev; x++) if (joinable[x]) pthread_join(th[x], NULL);
 	for (int x = 0; x < n_dev; x++) if (w[x].rc) rc = w[x].rc;
 	if (rc) goto DONE;
 	st->rng = starts[n_units];	/* where the serial stream stands after these initialisations */
@@ -515,7 +538,7 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 			       (int)((((int)r.seconds_run) % 3600) / 60), ((int)r.seconds_run) % 60, st->sum.max_logL, st->sum.n_maxll_times, o->em.seed);
 	}
 	/* the winner's parameters live on the device that fitted it */
-	if (st->sum.best_unit >= 0 && (keep_mle || (!bootstrap && o->write_files))) {
+	if (st->sum.best_unit >= 0 && (keep_mle || (!bootstrap && o->write_files) || o->afile)) {
 		const shard_worker *own = &w[st->sum.best_unit % n_dev];
 		if (own->best_unit != st->sum.best_unit) { fprintf(stderr, "ERROR [mc_main.c]: owner of the best unit does not hold it\n"); rc = MCHIP_ERR_STATE; goto DONE; }
 		if (keep_mle) {
@@ -527,14 +550,23 @@ static int maximize_likelihood_sharded(const mc_cli_options *o, const mc_cli_dat
 		}
 		if (!bootstrap && o->write_files) {
 			mc_fit_view fv = { K, res[st->sum.best_unit].converged, st->sum.max_logL, st->sum.aic, st->sum.bic, own->q, own->p, own->sik };
-			mc_partition(d, &fv, NULL, count_K);
+			mc_partition(d, &fv, st->I_K, count_K);
 			rc = mc_write_results(o, d, &fv, count_K);
+		}
+		if (!rc && o->afile) {	/* multiclust.c:602-612: the index of the serial loop's last improvement = the best unit's */
+			if (!o->write_files) {
+				mc_fit_view fv = { K, res[st->sum.best_unit].converged, st->sum.max_logL, st->sum.aic, st->sum.bic, own->q, own->p, own->sik };
+				mc_partition(d, &fv, st->I_K, count_K);
+			}
+			int fits = 1;
+			for (int x = 0; x < d->I; x++) if (st->I_K[x] >= K) fits = 0;
+			if (fits) st->arand = mc_adjusted_rand(d->I, st->pK, K, st->partition_from_file, st->I_K);
 		}
 	}
 DONE:
 	if (w) for (int x = 0; x < n_dev; x++) { free(w[x].q); free(w[x].p); free(w[x].sik); }
 	if (tab) for (int x = 0; x < n_gpus; x++) free(tab[x]);
-	free(w); free(th); free(res); free(tab); free(count_K); free(starts);
+	free(w); free(th); free(joinable); free(res); free(tab); free(count_K); free(starts);
 	return rc;
 }
 
@@ -627,14 +659,18 @@ static void *bs_main(void *arg)
 	ow.n_gpus = 0;			/* the fits of a replicate stay on this device, on this worker's stream */
 	ow.n_streams = 1;
 	mc_model *kept[2] = { NULL, NULL };
+	int *own_I_K = malloc(sizeof(int) * (size_t)(w->d->I > 0 ? w->d->I : 1));	/* -A: the partition record is per worker */
+	if (!own_I_K) { w->rc = MCHIP_ERR_ALLOC; return NULL; }
+	memcpy(own_I_K, w->st->I_K, sizeof(int) * (size_t)w->d->I);
 	for (int b = w->index; b < w->o->n_bootstrap; b += w->n_dev) {
 		run_state ls = *w->st;
 		ls.sim_models = kept;
+		ls.I_K = own_I_K;
 		mc_simulation gen;
 		size_t len = 0;
 		ls.mle_q = w->st->mle_q; ls.mle_p = w->st->mle_p;	/* read only */
 		mc_rng_jump(&ls.rng, (uint64_t)b * w->draws_per_replicate);
-		if (!(ls.out = open_memstream(&w->text[b], &len))) { w->rc = MCHIP_ERR_ALLOC; return NULL; }
+		if (!(ls.out = open_memstream(&w->text[b], &len))) { w->rc = MCHIP_ERR_ALLOC; free(own_I_K); return NULL; }
 		fprintf(ls.out, "Bootstrap dataset %d (of %d):", b + 1, w->o->n_bootstrap);
 		mc_simulation_begin(&gen, &ow.em, w->md, ls.mle_K, ls.mle_q, ls.mle_p, &ls.rng);
 		w->rc = estimate_model(&ow, w->d, w->md, &ls, 1, NULL, &gen);
@@ -644,6 +680,7 @@ static void *bs_main(void *arg)
 	}
 	mc_model_free(kept[0]);
 	mc_model_free(kept[1]);
+	free(own_I_K);
 	return NULL;
 }
 
@@ -654,17 +691,19 @@ static int run_bootstrap_sharded(const mc_cli_options *o, const mc_cli_data *d, 
 	const uint64_t units0 = st->null_K == 1 ? 1 : (uint64_t)o->n_init, units1 = (uint64_t)o->n_init;
 	bs_worker *w = calloc((size_t)n_dev, sizeof *w);
 	pthread_t *th = calloc((size_t)n_dev, sizeof *th);
+	int *joinable = calloc((size_t)n_dev, sizeof *joinable);
 	double *ts = calloc((size_t)B, sizeof *ts), **tab = calloc((size_t)n_gpus, sizeof *tab);
 	char **text = calloc((size_t)B, sizeof *text);
 	int rc = 0, ntime = 0;
-	if (!w || !th || !ts || !tab || !text) { rc = MCHIP_ERR_ALLOC; goto DONE; }
+	if (!w || !th || !joinable || !ts || !tab || !text) { rc = MCHIP_ERR_ALLOC; goto DONE; }
 	for (int x = 0; x < n_dev; x++) {
 		w[x].o = o; w[x].d = d; w[x].md = md; w[x].st = st; w[x].index = x; w[x].n_dev = n_dev;
 		w[x].draws_per_replicate = mc_bootstrap_draws(&o->em, md) + (units0 + units1) * per_init;
 		w[x].ts = ts; w[x].text = text;
-		if (pthread_create(&th[x], NULL, bs_main, &w[x])) { bs_main(&w[x]); th[x] = 0; }
+		if (pthread_create(&th[x], NULL, bs_main, &w[x])) bs_main(&w[x]);
+		else joinable[x] = 1;
 	}
-	for (int x = 0; x < n_dev; x++) if (th[x]) pthread_join(th[x], NULL);
+	for (int x = 0; x < n_dev; x++) if (joinable[x]) pthread_join(th[x], NULL);
 	for (int x = 0; x < n_dev; x++) if (w[x].rc) rc = w[x].rc;
 	if (rc) goto DONE;
 	mc_rng_jump(&st->rng, (uint64_t)B * w[0].draws_per_replicate);
@@ -688,7 +727,7 @@ static int run_bootstrap_sharded(const mc_cli_options *o, const mc_cli_data *d, 
 DONE:
 	if (tab) for (int x = 0; x < n_gpus; x++) free(tab[x]);
 	if (text) for (int b = 0; b < B; b++) free(text[b]);
-	free(w); free(th); free(ts); free(tab); free(text);
+	free(w); free(th); free(joinable); free(ts); free(tab); free(text);
 	return rc;
 }
 
@@ -698,9 +737,17 @@ int main(int argc, const char **argv)
 	mc_cli_data d;
 	run_state st;
 	int rc;
+	/* Every line leaves the process when it is complete, also into a pipe (same bytes as the reference's, earlier): a run that
+	 * stops making progress has then said how far it got.  MC_WATCHDOG_S=<s>: leave with status 3 and a report of where every
+	 * thread stands once nothing has happened for s seconds (mc_watchdog.c). */
+	setvbuf(stdout, NULL, _IOLBF, 0);
+	mc_watchdog_from_env();
+	mchip_progress_note("parse_options");
 	defaults(&o);
 	if ((rc = parse_options(&o, argc, argv))) return rc;	/* -h included: the reference's -h leaves with status 1 */
+	mchip_progress_note("mc_read_structure");
 	if ((rc = mc_read_structure(&o, &d))) return rc;
+	mchip_progress_note("estimate_model");
 	if (o.em.verbosity >= MC_TALKATIVE)
 		fprintf(stderr, "INFO: Finished reading data: %d %d-ploid individuals at %d loci.\n", d.I, d.ploidy, d.L);
 	mc_data md = { d.I, d.L, d.ploidy, d.uniquealleles, d.geno, NULL };
@@ -712,6 +759,8 @@ int main(int argc, const char **argv)
 	if (!o.target_ll && !o.target_revisit && !o.em.n_seconds && !o.n_init) o.n_init = 1;
 	if (!o.em.n_rand_em_init) o.em.initialization_procedure = MC_INIT_NOTHING;	/* -m 0 (multiclust.c:1549-1550) */
 	memset(&st, 0, sizeof st);
+	if (!(st.I_K = calloc((size_t)d.I, sizeof *st.I_K))) return MC_EXIT_MEMORY_ALLOCATION;
+	if (o.afile && (rc = mc_read_afile(o.afile, d.I, &st.partition_from_file, &st.pK))) return rc;	/* synchronize's last step (multiclust.c:889-890) */
 	st.out = stdout;
 	mchip_comm *run_comm = NULL;
 	st.comm = &run_comm;
@@ -727,7 +776,7 @@ int main(int argc, const char **argv)
 		double sum_ll = 0, sum_ll2 = 0, sum_init = 0, sum_init2 = 0, sum_iter = 0, sum_iter2 = 0, esec = 0;
 		double sum_aic_K = 0, sum_aic_K2 = 0, sum_bic_K = 0, sum_bic_K2 = 0;
 		double max_ll = -INFINITY, min_aic = 0, min_bic = 0, first_ll = -INFINITY;
-		const double max_ar = 0, max_ll_rand = 0, sum_ar = 0, sum_ar2 = 0;	/* adjusted Rand index: needs -A (refused); its fields stay 0 */
+		double max_ar = -1, max_ll_rand = 0, sum_ar = 0, sum_ar2 = 0;	/* adjusted Rand index (-A); without it model::arand stays 0 */
 		int n = 0, conv = 0, reached = 0, first_hit = 0, max_init = 0, max_iter = 0, enough = o.repeat_seconds ? 0 : 1, total;
 		char ab[16];
 		while (n < o.n_repeat || !enough) {
@@ -739,10 +788,13 @@ int main(int argc, const char **argv)
 				max_ll = st.sum.max_logL;
 				min_aic = st.sum.aic;
 				min_bic = st.sum.bic;
+				max_ll_rand = st.arand;
 				memset(&probe, 0, sizeof probe);
 				probe.logL = st.sum.max_logL;	/* converged(opt, mod, first_ll) compares with the model's current logL */
 				if (!mc_converged(&o.em, &probe, first_ll)) { first_ll = st.sum.max_logL; first_hit = n; }
 			}
+			if (st.arand > max_ar) max_ar = st.arand;	/* multiclust.c:252-253 */
+			if (o.afile) { sum_ar += st.arand; sum_ar2 += st.arand * st.arand; }
 			sum_init += st.sum.n_init; sum_init2 += (double)st.sum.n_init * st.sum.n_init;
 			sum_iter += st.sum.n_total_iter; sum_iter2 += (double)st.sum.n_total_iter * st.sum.n_total_iter;
 			sum_aic_K += st.aic_K; sum_aic_K2 += (double)st.aic_K * st.aic_K;
@@ -829,8 +881,10 @@ int main(int argc, const char **argv)
 		printf("p-value to reject H0: K=%d is %f\n", st.null_K, (double)(ntime / o.n_bootstrap));
 	}
 END:
+	mchip_progress_note("end of main: freeing");
 	if (run_comm) mchip_comm_destroy(run_comm);
-	free(st.mle_q); free(st.mle_p);
+	free(st.mle_q); free(st.mle_p); free(st.I_K); free(st.partition_from_file);
 	mc_free_data(&d);
+	mchip_progress_note("returning from main: the HIP runtime's own teardown follows");
 	return rc;
 }

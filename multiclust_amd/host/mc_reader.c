@@ -180,7 +180,7 @@ static double now_s(void)
 	clock_gettime(CLOCK_MONOTONIC, &t);
 	return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
-#define PHASE(name) do { if (timing) { double t_ = now_s(); fprintf(stderr, "INFO [mc_reader.c]: %-18s %.3f s\n", name, t_ - t_phase); t_phase = t_; } } while (0)
+#define PHASE(name) do { mchip_progress_note("mc_read_structure: after " name); if (timing) { double t_ = now_s(); fprintf(stderr, "INFO [mc_reader.c]: %-18s %.3f s\n", name, t_ - t_phase); t_phase = t_; } } while (0)
 
 static int n_threads(size_t work)
 {
@@ -297,15 +297,17 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 		const int nt = n_threads((size_t)nhap * (size_t)L);
 		parse_job jobs[64];
 		pthread_t th[64];
+		int joinable[64] = { 0 };	/* (a pthread_t has no "none" value) */
 		const size_t per = (ndata + (size_t)nt - 1) / (size_t)nt;
 		int perr = RD_OK;
 		for (int t = 0; t < nt; t++) {
 			const size_t lo = (size_t)t * per, hi = lo + per < ndata ? lo + per : ndata;
 			jobs[t] = (parse_job){ ls + first, le + first, lo < ndata ? lo : ndata, hi, L, pl, dat->interleaved, opt->missing_value, dat->IL, RD_OK };
-			if (nt == 1 || pthread_create(&th[t], NULL, parse_main, &jobs[t])) { parse_main(&jobs[t]); th[t] = 0; }
+			if (nt == 1 || pthread_create(&th[t], NULL, parse_main, &jobs[t])) parse_main(&jobs[t]);
+			else joinable[t] = 1;
 		}
 		for (int t = 0; t < nt; t++) {
-			if (th[t]) pthread_join(th[t], NULL);
+			if (joinable[t]) pthread_join(th[t], NULL);
 			if (!perr) perr = jobs[t].err;
 		}
 		if (perr == RD_SHORT_LINE) { rc = FAIL("failed to read a locus in file '%s'.  Check option -R.", opt->filename); goto DONE; }
@@ -325,15 +327,17 @@ int mc_read_structure(const mc_cli_options *opt, mc_cli_data *dat)
 		const int nt = n_threads((size_t)nhap * (size_t)L);
 		locus_job jobs[64];
 		pthread_t th[64];
+		int joinable[64] = { 0 };
 		const int per = ((L + nt - 1) / nt + LOCUS_BLOCK - 1) / LOCUS_BLOCK * LOCUS_BLOCK;
 		int lerr = RD_OK;
 		for (int t = 0; t < nt; t++) {
 			const int lo = t * per < L ? t * per : L, hi = lo + per < L ? lo + per : L;
 			jobs[t] = (locus_job){ dat->IL, I, L, pl, lo, hi, dat->uniquealleles, dat->L_alleles, dat->geno, 0, 0, RD_OK };
-			if (nt == 1 || pthread_create(&th[t], NULL, locus_main, &jobs[t])) { locus_main(&jobs[t]); th[t] = 0; }
+			if (nt == 1 || pthread_create(&th[t], NULL, locus_main, &jobs[t])) locus_main(&jobs[t]);
+			else joinable[t] = 1;
 		}
 		for (int t = 0; t < nt; t++) {
-			if (th[t]) pthread_join(th[t], NULL);
+			if (joinable[t]) pthread_join(th[t], NULL);
 			if (!lerr) lerr = jobs[t].err;
 			if (jobs[t].missing_data) dat->missing_data = 1;
 			if (jobs[t].M > dat->M) dat->M = jobs[t].M;

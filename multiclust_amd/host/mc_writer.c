@@ -11,6 +11,7 @@
  */
 #include "mc_cli.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -45,6 +46,71 @@ void mc_partition(const mc_cli_data *dat, const mc_fit_view *fit, int *I_K, int 
 		if (I_K) I_K[i] = best;
 		count_K[best]++;
 	}
+}
+
+int mc_read_afile(const char *path, int I, int **labels, int *pK)
+{
+	/* read_file.c:970-999 */
+	FILE *fp = fopen(path, "r");
+	int *lab, top = 0;
+	*labels = NULL;
+	*pK = 0;
+	if (!fp) {
+		fprintf(stderr, "ERROR [mc_writer.c::mc_read_afile]: could not open file '%s'\n", path);
+		return MC_EXIT_FILE_OPEN_ERROR;
+	}
+	if (!(lab = malloc(sizeof(int) * (size_t)(I > 0 ? I : 1)))) { fclose(fp); return MC_EXIT_MEMORY_ALLOCATION; }
+	for (int i = 0; i < I; i++) {
+		if (fscanf(fp, "%d", &lab[i]) != 1) {
+			fprintf(stderr, "ERROR [mc_writer.c::mc_read_afile]: format of partition file '%s': %d labels wanted, %d found\n", path, I, i);
+			fclose(fp);
+			free(lab);
+			return MC_EXIT_FILE_FORMAT_ERROR;
+		}
+		lab[i]--;
+		/* (a label below 1 indexes in front of the reference's contingency table: refused here) */
+		if (lab[i] < 0) {
+			fprintf(stderr, "ERROR [mc_writer.c::mc_read_afile]: partition file '%s': labels start at 1\n", path);
+			fclose(fp);
+			free(lab);
+			return MC_EXIT_FILE_FORMAT_ERROR;
+		}
+		if (lab[i] > top) top = lab[i];
+	}
+	fclose(fp);
+	*labels = lab;
+	*pK = top + 1;
+	return 0;
+}
+
+double mc_adjusted_rand(int n, int k1, int k2, const int *cl1, const int *cl2)
+{
+	/* multiclust.c:1903-1985, ADJUSTED_RAND_INDEX branch: the same sums in the same order */
+	double *nmat = calloc((size_t)k1 * (size_t)k2 + 1, sizeof *nmat);
+	double *sumtr = calloc((size_t)k1 + 1, sizeof *sumtr), *sumpr = calloc((size_t)k2 + 1, sizeof *sumpr);
+	double nidot2sum = 0, nij2sum = 0, ndotj2sum = 0, index = NAN;
+	if (nmat && sumtr && sumpr) {
+		for (int i = 0; i < n; i++) nmat[(size_t)cl1[i] * k2 + cl2[i]] += 1;	/* (ints in the reference: exact either way) */
+		for (int i = 0; i < k1; i++)
+			for (int j = 0; j < k2; j++) sumtr[i] += nmat[(size_t)i * k2 + j];
+		for (int j = 0; j < k2; j++)
+			for (int i = 0; i < k1; i++) sumpr[j] += nmat[(size_t)i * k2 + j];
+		for (int i = 0; i < k1; i++) nidot2sum += sumtr[i] * (sumtr[i] - 1) / 2;
+		for (int i = 0; i < k1; i++)
+			for (int j = 0; j < k2; j++) {
+				/* nmat[i][j] * (nmat[i][j] - 1) / 2.0 with int nmat: an integer product (exact here up to any count; the
+				 * reference's overflows past 46 340 individuals in one cell), then divided in double */
+				const long long c = (long long)nmat[(size_t)i * k2 + j];
+				nij2sum += (double)(c * (c - 1)) / 2.0;
+			}
+		for (int j = 0; j < k2; j++) ndotj2sum += sumpr[j] * (sumpr[j] - 1) / 2.0;
+		const double term3 = nidot2sum * ndotj2sum / (n * (n - 1.) / 2.);
+		const double term1 = nij2sum - term3;
+		const double term2 = (nidot2sum + ndotj2sum) / 2 - term3;
+		index = term1 / term2;
+	}
+	free(nmat); free(sumtr); free(sumpr);
+	return index;
 }
 
 int mc_write_results(const mc_cli_options *opt, const mc_cli_data *dat, const mc_fit_view *fit, const int *count_K)

@@ -71,6 +71,7 @@ static void bind(options *opt, data *dat, model *mod)
 	int fresh = 0;
 	if (opt->pfile || opt->qfile) bind_fatal("starting values from files (-p/-q) are not bound");
 	if (B.dat != dat) {
+		mc_watchdog_from_env();		/* MC_WATCHDOG_S, as the drop-in command line: tests/procutil.py sets it */
 		unbind();
 		free(B.flat); free(B.sim);
 		B.sim = NULL;

@@ -35,6 +35,9 @@ int mchip_step_dots(mchip_context*c,int a,double*l){(void)c;(void)a;(void)l;retu
 int mchip_secant_dots(mchip_context*c,int a,int b,double*l){(void)c;(void)a;(void)b;(void)l;return 2;}
 int mchip_accel_update(mchip_context*c,int a,int b,int d,double s,int q){(void)c;(void)a;(void)b;(void)d;(void)s;(void)q;return 2;}
 int mchip_multisecant_update(mchip_context*c,int a,int b,int d,int n,const int*v,const double*x,const double*y){(void)c;(void)a;(void)b;(void)d;(void)n;(void)v;(void)x;(void)y;return 2;}
+static unsigned long long stub_events;
+int mchip_progress_note(const char *w){(void)w;stub_events++;return 0;}
+int mchip_progress_report(char *b,int n,unsigned long long *e){if(e)*e=stub_events;if(b&&n>0)snprintf(b,(size_t)n,"thread 0: stub\n");return 0;}
 void mc_test_draw_partition(uint8_t *assign, size_t n, int K, mc_rng *rng);
 int main(int argc, char **argv)
 {
@@ -52,6 +55,22 @@ int main(int argc, char **argv)
 			o.path = "/tmp/asan"; o.filename_file = "x.stru"; o.em.admixture = 1;
 			mc_partition(&d, &fv, NULL, cnt);
 			mc_write_results(&o, &d, &fv, cnt);
+			{	/* -A: a partition file of I labels, the adjusted Rand index against the MAP partition, the failure paths */
+				int *I_K = calloc((size_t)d.I, sizeof *I_K), *lab = NULL, pK = 0;
+				FILE *af = fopen("/tmp/asan/partition.txt", "w");
+				for (int i = 0; i < d.I; i++) fprintf(af, "%d\n", 1 + i % 4);
+				fclose(af);
+				mc_partition(&d, &fv, I_K, cnt);
+				if (mc_read_afile("/tmp/asan/partition.txt", d.I, &lab, &pK) || pK != 4) { printf("afile failed\n"); return 1; }
+				const double ar = mc_adjusted_rand(d.I, pK, K, lab, I_K), self = mc_adjusted_rand(d.I, pK, pK, lab, lab);
+				printf("adjusted rand %f, of a partition with itself %f\n", ar, self);
+				if (!(self > 0.999999 && self < 1.000001)) return 1;
+				free(lab);
+				if (mc_read_afile("/tmp/asan/partition.txt", d.I + 1, &lab, &pK) != MC_EXIT_FILE_FORMAT_ERROR || lab) return 1;
+				if (mc_read_afile("/tmp/asan/absent.txt", d.I, &lab, &pK) != MC_EXIT_FILE_OPEN_ERROR || lab) return 1;
+				free(I_K);
+				mc_watchdog_report(stdout, 0.0);	/* the report a stalled run would leave */
+			}
 			free(q); free(p); free(s);
 			/* the host-side walks of Rand-EM (allele-count table, center draws, unmatched-copy counts) and of the mixture
 			 * model's random centers: skipping initialisations touches no device */

@@ -23,6 +23,8 @@ CASES = [
     (["-f", MULTI, "-a", "-k", "2", "-T", "-3"], 10),
     (["-f", MULTI, "-p", "3", "-a", "-k", "2"], 7),          # 80 lines are not a multiple of ploidy 3: FILE_FORMAT_ERROR
     (["-h"], 1),                                             # help leaves through the usage-error path
+    (["-f", MULTI, "-a", "-k", "2", "-A", "/nonexistent/partition.txt"], 5),     # -A: read_afile() is synchronize()'s last step
+    (["-f", MULTI, "-a", "-k", "2", "-A", MULTI], 7),        # ... a file that does not start with I integers: FILE_FORMAT_ERROR
 ]
 
 

@@ -9,6 +9,8 @@ import sys
 import numpy as np
 import pytest
 
+from procutil import run_program
+
 from golden_util import GOLD, Golden
 
 pytestmark = pytest.mark.gpu
@@ -33,9 +35,8 @@ def test_c4_units_agree_with_command_line(tmp_path):
     from multiclust_amd import host
     g = Golden("multi_admix_k4")
     n_units, cycles = 6, 8
-    res = subprocess.run([BIN, "-f", os.path.join(GOLD, "data", "multi.stru"), "-d", str(tmp_path), "-a", "-k", "4", "-n", str(n_units),
-                          "-s", "3", "-T", str(2 * cycles - 1), "-r", str(bench.SEED)],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    res = run_program([BIN, "-f", os.path.join(GOLD, "data", "multi.stru"), "-d", str(tmp_path), "-a", "-k", "4", "-n", str(n_units),
+                       "-s", "3", "-T", str(2 * cycles - 1), "-r", str(bench.SEED)], timeout=300)
     assert res.returncode == 0, res.stderr
     cli = [(float(m.group(1)), int(m.group(2))) for m in
            re.finditer(r"initialization = \d+: (-?\d+\.\d+) \(.*?\) in\s+(\d+) iterations", res.stdout)]
@@ -56,9 +57,8 @@ def test_c5_replicates_agree_with_command_line(tmp_path):
     import bench
     g = Golden("tetra_admix_k3")
     n_rep, budget = 4, 9
-    res = subprocess.run([BIN, "-f", os.path.join(GOLD, "data", "tetra.stru"), "-d", str(tmp_path), "-p", "4", "-a", "-k", "3", "-n", "1",
-                          "-b", str(n_rep), "-T", str(budget), "-r", str(bench.SEED)],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    res = run_program([BIN, "-f", os.path.join(GOLD, "data", "tetra.stru"), "-d", str(tmp_path), "-p", "4", "-a", "-k", "3", "-n", "1",
+                       "-b", str(n_rep), "-T", str(budget), "-r", str(bench.SEED)], timeout=300)
     assert res.returncode == 0, res.stderr
     cli = [(float(a), float(b)) for a, b in re.findall(r"test statistics bs=(-?\d+\.\d+) obs=(-?\d+\.\d+)", res.stdout)]
     assert len(cli) == n_rep

@@ -8,6 +8,8 @@ import subprocess
 import numpy as np
 import pytest
 
+from procutil import run_program
+
 from golden_util import GOLD
 
 pytestmark = pytest.mark.gpu
@@ -25,7 +27,7 @@ def run_cli(case, tmp_path, extra=()):
     # -d with its trailing slash: the reference's own mixture writers size their file-name buffers without the separator they
     # insert when it is missing (write_file.c:628-640,707-711), one byte short; tests/test_gpu_refbind.py runs that code
     cmd = [BIN, "-f", stru, "-d", os.path.join(str(tmp_path), "")] + rest + list(extra)
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    res = run_program(cmd, timeout=300)
     assert res.returncode == 0, res.stderr
     run_cli.last_stderr = res.stderr
     return gdir, CLOCK.sub("HH:MM:SS", res.stdout.replace(stru, os.path.basename(stru)))
@@ -94,8 +96,7 @@ def test_cli_k_range_and_quiet_mode(tmp_path):
     """-1/-2 K range (the reference itself aborts after the first K, so there is no golden: structural checks),
     -M prints only the maximum log likelihood."""
     stru = os.path.join(GOLD, "data", "multi.stru")
-    res = subprocess.run([BIN, "-f", stru, "-a", "-1", "2", "-2", "4", "-n", "2", "-r", "3", "-s", "3", "-d", str(tmp_path)],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    res = run_program([BIN, "-f", stru, "-a", "-1", "2", "-2", "4", "-n", "2", "-r", "3", "-s", "3", "-d", str(tmp_path)], timeout=300)
     assert res.returncode == 0, res.stderr
     lines = res.stdout.strip().split("\n")
     assert len(lines) == 3 * (2 + 1)
@@ -103,8 +104,7 @@ def test_cli_k_range_and_quiet_mode(tmp_path):
     assert lls[0] < lls[1] < lls[2]                                    # more clusters fit better
     for K in (2, 3, 4):
         assert os.path.exists(tmp_path / ("multi.stru.admix.K=%d.pklm.txt" % K))
-    res = subprocess.run([BIN, "-f", stru, "-a", "-k", "2", "-n", "1", "-M", "-d", str(tmp_path)],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    res = run_program([BIN, "-f", stru, "-a", "-k", "2", "-n", "1", "-M", "-d", str(tmp_path)], timeout=300)
     # -M sets verbosity to SILENT (= 1, still non-zero), so the reference prints the summary line and then max_logL
     out = res.stdout.strip().split("\n")
     assert res.returncode == 0 and len(out) == 2
@@ -132,7 +132,7 @@ def test_cli_bootstrap_device_host_and_sharded_agree(tmp_path, monkeypatch):
             monkeypatch.setenv("MC_FORCE_SHARDED", "1")
             monkeypatch.setenv("MC_TRACE_EXCHANGE", "1")
             extra = ["--gpus", "1"]
-        res = subprocess.run(cmd + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        res = run_program(cmd + extra, timeout=600)
         assert res.returncode == 0, res.stderr
         if mode == "sharded":
             # H0 and HA fits of the observed data (one all-reduce each), then the replicates' test statistics: one communicator,

@@ -13,6 +13,8 @@ import sys
 
 import pytest
 
+import procutil
+
 import test_gpu_cli as cli
 
 sys.path.insert(0, os.path.join(cli.ROOT, "oracle"))
@@ -25,22 +27,11 @@ SIZE_LIMIT = SIZE ** 3                                   # (a hexaploid 328 x 23
 
 
 def run_program(cmd, cwd, timeout=None):
-    """One launch in about 4 000 of these soaks -- a 60-locus mixture fit that takes 0.3 s -- did not return within 300 s, on a box
-    where everything before and after ran at normal speed; run again with -v 4 it finished at once with the reference's output
-    line for line (scripts/diag/hang184.py), and 1 500 launches of that very fit in a loop all returned within 0.4 s
-    (scripts/diag/hang_stress.sh, which records the threads' wait channels of a launch that does not).  Not reproduced, cause
-    unknown (nothing in the host code waits on anything but pthread_join and stream synchronisation).  A launch that exceeds the limit is repeated once, with a warning in the report;
-    a second timeout fails the test."""
-    timeout = timeout or 120 * SIZE_LIMIT
-    for attempt in (1, 2):
-        try:
-            return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=cwd)
-        except subprocess.TimeoutExpired:
-            if attempt == 2:
-                raise
-            import warnings
-            warnings.warn("no return within %d s, launched again: %s" % (timeout, " ".join(cmd)))
-
+    """One launch, never a second one (tests/procutil.py): a program that does not return within the limit fails the test, with
+    what it had printed, where each of its threads stood and -- for ours, which runs under MC_WATCHDOG_S -- the library call it
+    was waiting in.  (One launch in about 4 000 of round 3's soaks, a 60-locus mixture fit of 0.3 s, did not return within 300 s
+    and left no such record: DESIGN.md section 9.)"""
+    return procutil.run_program(cmd, cwd=cwd, timeout=timeout or 120 * SIZE_LIMIT)
 
 
 
@@ -209,8 +200,15 @@ def test_bookkeeping_options_against_the_reference_program(args, n_files, tmp_pa
     516-653): same lines, same numbers (plain EM: iteration counts exactly), same files.  Seconds are masked."""
     stru = os.path.join(cli.GOLD, "data", "multi.stru")
     (ref_lines, ref_dir), (got_lines, got_dir) = run_both(tmp_path, args.split(), stru)
+    compare_bookkeeping_lines(ref_lines, got_lines, stru, "-w" in args.split())
+    ref_files, got_files = (sorted(f for f in os.listdir(x) if not f.endswith("_mix_popq.popq")) for x in (ref_dir, got_dir))
+    assert ref_files == got_files and len(ref_files) == n_files, (ref_files, got_files)
+    for fn in ref_files:
+        cli.compare_file(os.path.join(ref_dir, fn), os.path.join(got_dir, fn), 2e-6 if not fn.endswith("out.txt") else 1e-5)
+
+
+def compare_bookkeeping_lines(ref_lines, got_lines, stru, timed):
     assert len(ref_lines) == len(got_lines), (ref_lines, got_lines)
-    timed = "-w" in args.split()
     for r, g in zip(ref_lines, got_lines):
         if timed and r.startswith("Average time:"):
             assert g.startswith("Average time:")
@@ -227,11 +225,35 @@ def test_bookkeeping_options_against_the_reference_program(args, n_files, tmp_pa
             except ValueError:
                 assert a == b, (r, g)
                 continue
-            assert abs(fa - fb) <= max(2e-5, 1e-9 * abs(fa)), (r, g)
-    ref_files, got_files = (sorted(f for f in os.listdir(x) if not f.endswith("_mix_popq.popq")) for x in (ref_dir, got_dir))
-    assert ref_files == got_files and len(ref_files) == n_files, (ref_files, got_files)
-    for fn in ref_files:
-        cli.compare_file(os.path.join(ref_dir, fn), os.path.join(got_dir, fn), 2e-6 if not fn.endswith("out.txt") else 1e-5)
+            assert abs(fa - fb) <= max(2e-5, 1e-9 * abs(fa)) or (fa != fa and fb != fb), (r, g)
+
+
+@pytest.mark.skipif(not os.access(REFBIN, os.X_OK), reason="oracle/_ref/multiclust_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("partition", ["locales", "random3", "one", "every_other"])
+@pytest.mark.parametrize("args", [
+    "-a -k 3 -n 3 -r 5 -d ./",                   # the index of the best initialisation's MAP partition, in print_model_state()'s line
+    "-k 3 -n 2 -r 5 -d ./",                      # mixture model: partition_mixture (argmax of vik)
+    "-a -1 2 -2 3 -n 2 -r 7 -w n 3",             # -w: no files, so the partition is taken for -A alone; RAND statistics of the repetitions
+])
+def test_partition_file_and_adjusted_rand_index_against_the_reference_program(partition, args, tmp_path):
+    """-A <file>: cluster labels 1, 2, ... of the individuals (read_afile, read_file.c:970-999); whenever an initialisation
+    improves the maximum its MAP partition is compared with them (adj_rand, multiclust.c:602-612, 1903-1985) and the index takes
+    the place of "ND" in the summary line (728-731); -w reports its average, spread and maximum over the repetitions (252-266,
+    320-324).  Same lines as the unmodified reference program, on four partitions: the locales of the data file, three random
+    classes, one class (0 / 0: "nan" or "-nan", the sign is not compared), two alternating classes."""
+    stru = os.path.join(cli.GOLD, "data", "multi.stru")
+    rows = [ln.split() for ln in open(stru).read().strip().split("\n")[1:]]
+    rows = [r for r in rows if len(r) > 2 and r[0] != "-1"][::2]                    # one line per individual (diploid, two lines each)
+    pops = sorted(set(r[1] for r in rows))
+    rnd = random.Random(4)
+    labels = {"locales": [pops.index(r[1]) + 1 for r in rows], "random3": [rnd.randrange(3) + 1 for _ in rows],
+              "one": [1 for _ in rows], "every_other": [1 + x % 2 for x in range(len(rows))]}[partition]
+    afile = str(tmp_path / "partition.txt")
+    open(afile, "w").write("\n".join(str(x) for x in labels) + "\n")
+    (ref_lines, _), (got_lines, _) = run_both(tmp_path, args.split() + ["-A", afile], stru)
+    unsigned = [[ln.replace("-nan", "nan") for ln in lines] for lines in (ref_lines, got_lines)]
+    compare_bookkeeping_lines(unsigned[0], unsigned[1], stru, "-w" in args.split())
+    assert any(" ND " not in ln for ln in got_lines if ln.startswith(stru))         # the index is on the summary line
 
 
 @pytest.mark.skipif(not os.access(REFBIN, os.X_OK), reason="oracle/_ref/multiclust_ref not built (needs /root/reference at build time)")
@@ -342,7 +364,7 @@ def test_starting_values_from_files_against_the_reference_program(c, tmp_path):
         # exist (read_file.c:950, past the allocation) and carries on; this build refuses the combination
         d = tmp_path / "hip"
         d.mkdir()
-        res = subprocess.run([cli.BIN, "-f", stru] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, cwd=str(d))
+        res = run_program([cli.BIN, "-f", stru] + args, str(d), timeout=120)
         assert res.returncode == 11 and "-P needs two alleles at every locus" in res.stderr
         return
     (ref_lines, ref_dir), (got_lines, got_dir) = run_both(tmp_path, args, stru)

@@ -411,3 +411,33 @@ def test_large_k_mixture_and_shared_eta_models(ctx, I, L, K, pl, maxal, miss):
         assert abs(ll - mod.logL) <= max(1e-8, 1e-12 * abs(mod.logL)), ("c", s, ll, mod.logL)
         np.testing.assert_allclose(ctx.get_q(0), mod.q(0), rtol=1e-8, atol=1e-14)
         np.testing.assert_allclose(ctx.get_p(0), mod.p(0), rtol=1e-8, atol=1e-14)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("poison", ["nan", "-inf", "+inf"])
+def test_mixture_loglik_without_an_ordinary_term_is_nan_not_a_stall(ctx, poison):
+    """logL_mixture halves a scale until exp() stops overflowing (log_likelihood.c:212-221); for an individual whose every
+    log-sum is NaN or -inf (or one +inf) its maximum is infinite, inf / 2 = inf, and the reference never leaves that loop -- a
+    stuck process on the CPU, a wave the stream never gets back from on the device (k_mix_finalize).  No reference answer
+    exists: the individual's term is NaN here, so the log likelihood is NaN and stop() ends the run on "nan"
+    (em_alg.c:106-110).  The call returns; finite rows beside it and the next call are unaffected."""
+    I, L, K = 70, 90, 3
+    ua, geno = make_dataset(I, L, K, ploidy=2, max_alleles=3, seed=5)
+    _, p0 = random_params(I, ua, K, seed=9, lower_bound=1e-8)
+    eta = np.full(K, 1.0 / K)
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, admixture=0, do_projection=0, lower_bound=1e-8)
+    ctx.set_q(0, eta)
+    ctx.set_p(0, p0)
+    good = ctx.loglik(0)
+    assert np.isfinite(good)
+    bad = p0.copy()
+    col = int(geno[3, 0, 0])                                      # an allele individual 3 carries at the first locus
+    # a negative p (an extrapolated point with the projection off) has log = NaN; p = 0 has log = -inf in every cluster;
+    # p = +inf cannot come out of any step, but the loop's other way out of the ordinary numbers is closed too
+    bad[:, col] = {"nan": -0.25, "-inf": 0.0, "+inf": np.inf}[poison]
+    ctx.set_p(0, bad)
+    ll = ctx.loglik(0)                                            # log_likelihood(): mode 1 of k_mix_finalize
+    assert np.isnan(ll)
+    ctx.set_p(0, p0)
+    assert ctx.loglik(0) == good                                  # the stream came back, and with the same bits

@@ -9,6 +9,8 @@ import subprocess
 import numpy as np
 import pytest
 
+from procutil import run_program
+
 import oracle_bind as ob
 from golden_util import GOLD, RANDEM_CASES, Golden
 from multiclust_amd import host
@@ -109,7 +111,7 @@ def test_cli_randem_serial_sharded_and_reference_fit(tmp_path, monkeypatch):
         if sharded:
             monkeypatch.setenv("MC_FORCE_SHARDED", "1")
             extra = ["--gpus", "1", "--streams", "2"]
-        res = subprocess.run(cmd + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        res = run_program(cmd + extra, timeout=300)
         assert res.returncode == 0, res.stderr
         outs.append(re.sub(r"\d\d:\d\d:\d\d", "HH:MM:SS", res.stdout))
     first = re.search(r"initialization = 0: (-?\d+\.\d+) \((\w+ ?\w*)\) in\s+(\d+) iterations", outs[0])
@@ -129,14 +131,13 @@ def test_cli_randem_with_bootstrap_and_mixture(tmp_path, monkeypatch):
         if sharded:
             monkeypatch.setenv("MC_FORCE_SHARDED", "1")
             extra = ["--gpus", "1"]
-        res = subprocess.run([BIN, "-f", stru, "-d", str(tmp_path), "-a", "-k", "3", "-r", "5", "-n", "2", "-b", "2", "--randem", "-m", "3", "-T", "30"] + extra,
-                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        res = run_program([BIN, "-f", stru, "-d", str(tmp_path), "-a", "-k", "3", "-r", "5", "-n", "2", "-b", "2", "--randem", "-m", "3", "-T", "30"] + extra,
+                          timeout=600)
         assert res.returncode == 0, res.stderr
         assert res.stdout.count("Bootstrap dataset") == 2 and "p-value to reject H0: K=2" in res.stdout
         outs.append(re.sub(r"\d\d:\d\d:\d\d", "HH:MM:SS", res.stdout))
     assert outs[0] == outs[1]
-    res = subprocess.run([BIN, "-f", stru, "-d", str(tmp_path), "-k", "3", "-r", "5", "-n", "2", "--randem", "-m", "4"],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    res = run_program([BIN, "-f", stru, "-d", str(tmp_path), "-k", "3", "-r", "5", "-n", "2", "--randem", "-m", "4"], timeout=600)
     assert res.returncode == 0, res.stderr
     g = Golden("multi_mix_k3_randem")           # same file, seed and model; 5 candidates there, 4 here: only the shape of the output
     assert res.stdout.count("initialization =") == 2 and "converged" in res.stdout

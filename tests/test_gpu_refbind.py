@@ -16,6 +16,8 @@ import os
 
 import pytest
 
+from procutil import run_program
+
 import test_gpu_cli as cli
 
 pytestmark = pytest.mark.gpu
@@ -56,8 +58,7 @@ def test_bound_program_beside_the_unmodified_one_on_bootstrap_runs(args, tmp_pat
     for name, exe in (("ref", REFBIN), ("bound", BOUND)):
         d = tmp_path / name
         d.mkdir()
-        res = subprocess.run([exe, "-f", stru, "-d", os.path.join(str(d), "")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                             text=True, timeout=600, cwd=str(d))
+        res = run_program([exe, "-f", stru, "-d", os.path.join(str(d), "")] + args, cwd=str(d), timeout=600)
         assert res.returncode == 0, (name, res.stderr[-2000:])
         lines[name] = cli.CLOCK.sub("HH:MM:SS", res.stdout).strip().split("\n")
     assert len(lines["ref"]) == len(lines["bound"])

@@ -14,7 +14,7 @@ def test_host_c_code_is_sanitizer_clean(tmp_path):
     exe = str(tmp_path / "asan_host")
     host = os.path.join(ROOT, "multiclust_amd", "host")
     srcs = [os.path.join(ROOT, "tests", "asan_host_driver.c")] + [os.path.join(host, f) for f in
-                                                                  ("mc_reader.c", "mc_writer.c", "mc_fit.c", "mc_em.c", "mc_init.c")]
+                                                                  ("mc_reader.c", "mc_writer.c", "mc_fit.c", "mc_em.c", "mc_init.c", "mc_watchdog.c")]
     subprocess.run(["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
                     "-I" + os.path.join(ROOT, "include"), "-I" + host, "-o", exe] + srcs + ["-lm", "-lpthread"], check=True)
     data = os.path.join(ROOT, "tests", "golden", "data")
@@ -27,3 +27,4 @@ def test_host_c_code_is_sanitizer_clean(tmp_path):
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
     assert res.returncode == 0, res.stderr[-2000:]
     assert "ok 1" in res.stdout and "AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr
+    assert "of a partition with itself 1.000000" in res.stdout and "WATCHDOG [mc_watchdog.c]" in res.stdout
