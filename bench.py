@@ -471,10 +471,10 @@ def reference_leg(w, ua_s, geno_s, q0, p0, accel, iters, procs, budget_s, device
 # ------------------------------------------------------------------------------------------------ roofline object
 PASS_NAMES = ["column_pass", "individual_pass", "loglik_pass", "individual_dual_pass"]
 PASS_KERNELS = {"column_pass": ("k_column_counts", "k_column_counts (N-side sums)"),
-                "individual_pass": ("k_individual_sparse<2, true, false, true, false>", "k_individual_sparse (S-side sums + logL)"),
-                "loglik_pass": ("k_individual_sparse<2, false", "k_individual_sparse (stand-alone log likelihood)"),
-                "individual_dual_pass": ("k_individual_sparse<2, true, false, true, true>",
-                                         "k_individual_sparse, dual (S-side sums of the extrapolated point + logL of the second EM iterate)")}
+                "individual_pass": ("k_individual_sparse_w<2, true, false, true, false>", "k_individual_sparse_w (S-side sums + logL)"),
+                "loglik_pass": ("k_individual_sparse_w<2, false", "k_individual_sparse_w (stand-alone log likelihood)"),
+                "individual_dual_pass": ("k_individual_sparse_w<2, true, false, true, true>",
+                                         "k_individual_sparse_w, dual (S-side sums of the extrapolated point + logL of the second EM iterate)")}
 FP64_SUSTAINED_TF = 62.0     # v_fma_f64 stream on operands that keep changing, held for 5 s: 2.00-2.05 GHz (power management; 2.35 GHz
                              # and 71-74 TF/s on constant operands), 4.3-4.4 cycles per wave-instruction
                              # (profiles/r03_fp64_sustained_clock.txt); the spec peak assumes 2.4 GHz and 4.0
@@ -483,9 +483,19 @@ FP64_SUSTAINED_TF = 62.0     # v_fma_f64 stream on operands that keep changing, 
 def latest_traffic(tag):
     """HBM bytes per launch from the PMC passes of this same command in an EARLIER run (scripts/summarize_profile.py; corrected
     as MI355X_MICROARCH.md prescribes): (newest profiles/r*_<tag>_traffic.json, its name), or (None, None).  Counters cannot be
-    read inside a timed run; the line says where the figure comes from (`traffic_source`)."""
+    read inside a timed run; the line says where the figure comes from (`traffic_source`) and whether that file was taken from
+    the very library this run has loaded (`traffic_build_matches`: the file's `_build.library_sha256` against the library's)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_traffic.json" % tag)))
     return (json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)) if files else (None, None)
+
+
+def library_sha256():
+    import hashlib
+    from multiclust_amd import hip
+    try:
+        return hashlib.sha256(open(hip.lib_path(), "rb").read()).hexdigest()
+    except OSError:
+        return None
 
 
 def profile_begin(ctx):
@@ -493,7 +503,7 @@ def profile_begin(ctx):
     hip.load().mchip_profile_begin(ctx)
 
 
-def build_roofline(w, T, K, kernel_ms, launches, steps, it_per_s_per_gpu, nnz, traffic_table=None, traffic_file=None):
+def build_roofline(w, T, K, kernel_ms, launches, steps, it_per_s_per_gpu, nnz, traffic_table=None, traffic_file=None, lib_sha=None):
     """The line's `roofline` object from the library's HIP-event figures: kernel_ms[x] / launches[x] = summed duration and number
     of working launches of pass x (PASS_NAMES) over `steps` timed steps.  The dominant kernel is the pass with the most time per
     step; `achieved` / `peak` / `frac` are its ALGORITHMIC bytes per launch over its average launch time against the HBM peak
@@ -505,16 +515,23 @@ def build_roofline(w, T, K, kernel_ms, launches, steps, it_per_s_per_gpu, nnz, t
     name = PASS_NAMES[dom]
     ach = B[name] / (avg[dom] * 1e-3) / 1e9 if avg[dom] else 0.0
     flops_cell = 5 * K + 5                                   # flops per non-empty cell (+ one log)
-    traffic = None
+    traffic, traffic_build, pass_traffic = None, None, {}
     if traffic_table:
-        for kname, rec in traffic_table.items():
-            if kname.startswith(PASS_KERNELS[name][0]):
-                traffic = rec.get("hbm_bytes_per_launch_corrected")
-                break
+        traffic_build = traffic_table.get("_build")
+        for x in range(len(PASS_NAMES)):
+            for kname, rec in traffic_table.items():
+                if kname != "_build" and kname.startswith(PASS_KERNELS[PASS_NAMES[x]][0]):
+                    pass_traffic[PASS_NAMES[x]] = rec.get("hbm_bytes_per_launch_corrected")
+                    break
+        traffic = pass_traffic.get(name)
     return {
         "bound": "fp64-valu", "kernel": PASS_KERNELS[name][1],
         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_file if traffic is not None else None,
+        "traffic_build": traffic_build if traffic is not None else None,
+        "traffic_build_matches": (bool(traffic_build and lib_sha and traffic_build.get("library_sha256") == lib_sha)
+                                  if traffic is not None else None),
+        "pass_traffic": pass_traffic or None,
         "algorithmic_bytes_per_launch": B[name], "avg_launch_ms": avg[dom],
         "kernels_ms": {PASS_NAMES[x]: avg[x] for x in range(len(PASS_NAMES))},
         "kernels_ms_per_step": {PASS_NAMES[x]: per_step[x] for x in range(len(PASS_NAMES))},
@@ -545,8 +562,8 @@ def roofline_object(ctx, w, T, K, it_per_s_per_gpu, workload, nnz, steps):
     km = (C.c_double * hip.PROF_KINDS)()
     kl = (C.c_int * hip.PROF_KINDS)()
     hlib.mchip_profile_end(ctx, C.byref(total_ms), km, kl)
-    table, fname = latest_traffic("c3") if workload in ("c3", "c4") else (None, None)
-    return build_roofline(w, T, K, list(km), list(kl), steps, it_per_s_per_gpu, nnz, table, fname)
+    table, fname = latest_traffic("c3" if workload == "c4" else workload)
+    return build_roofline(w, T, K, list(km), list(kl), steps, it_per_s_per_gpu, nnz, table, fname, library_sha256())
 
 
 def data_counts(ctx):
@@ -655,6 +672,66 @@ def run_single_fit(args, env, name, ua, geno, steps, warmup, with_roofline=True)
                             "note": "the timed region's batch repeated right behind it; clocks differ from box to box by +-6 % "
                                     "(DESIGN.md 4.3), within a run by what this shows"}
     return out, fit, accel
+
+
+# ------------------------------------------------------------------------------------------------ c1: through the reader
+def write_structure(path, ua, geno):
+    """the synthetic genotype as a STRUCTURE file (read_file.c:38-300): a line of locus names, then `ploidy` lines per individual
+    (name, locale, one allele code per locus); allele index m of a locus is written as code m + 1"""
+    I, L, p = geno.shape
+    with open(path, "w") as f:
+        f.write(" ".join("loc%d" % (l + 1) for l in range(L)) + "\n")
+        for i in range(I):
+            for a in range(p):
+                f.write("ind%d pop%d %s\n" % (i, i % 3, " ".join(str(int(m) + 1) if m != 0xFF else "-9" for m in geno[i, :, a])))
+
+
+def run_c1_reader(env, iters=200):
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case: 100 diploid x 500 biallelic loci, -a -k 3, plain EM) on
+    the path a user's file takes: STRUCTURE text -> mc_read_structure (host/mc_reader.c) -> device layouts -> random
+    initialisation from the seed -> em() with -T `iters` (iters + 1 iterations, em_alg.c:150), the EM loop timed.  The drop-in
+    command line then runs the same file, seed and arguments as a child process; its printed log likelihood and iteration count
+    must be the timed fit's."""
+    import re
+    import tempfile
+    from multiclust_amd import host
+    w = WORKLOADS["c1"]
+    ua, geno = workload_data(w, env)
+    # every allele of a locus must occur for the reader's allele list (ascending codes seen in the file) to be the generator's
+    with tempfile.TemporaryDirectory(prefix="mcc1.") as d:
+        path = os.path.join(d, "c1.stru")
+        write_structure(path, ua, geno)
+        t0 = time.perf_counter()
+        rc, dat = host.read_structure(path, ploidy=w["ploidy"])
+        read_s = time.perf_counter() - t0
+        if rc:
+            raise SystemExit("c1: mc_read_structure failed (%d)" % rc)
+        fit = host.Fit(dat["ua"], dat["geno"], w["K"], device=env.local_rank, admixture=1, accel_scheme=0, verbosity=1, max_iter=iters,
+                       abs_error=1e-300)
+        for timed in (0, 1):                      # the first fit is the warm-up (graph capture, first-touch allocations)
+            fit.reset()
+            fit.initialize(SEED)
+            env.barrier(C.c_void_p(fit.mod.dev))
+            t0 = time.perf_counter()
+            fit.em()
+            dt = time.perf_counter() - t0
+        n_iter, logL = fit.mod.n_iter, fit.mod.logL
+        fit.close()
+        exe = os.path.join(ROOT, "multiclust_amd", "bin", "multiclust")
+        cli = {"ran": False}
+        if os.access(exe, os.X_OK):
+            t0 = time.perf_counter()
+            res = subprocess.run([exe, "-f", path, "-d", os.path.join(d, ""), "-a", "-k", str(w["K"]), "-n", "1", "-T", str(iters), "-r", str(SEED),
+                                  "-E", "1e-300"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            m = re.search(r"initialization = 0: (-?\d+\.\d+) \(.*?\) in\s+(\d+) iterations", res.stdout)
+            cli = {"ran": True, "rc": res.returncode, "wall_s": time.perf_counter() - t0,
+                   "logL": float(m.group(1)) if m else None, "n_iter": int(m.group(2)) if m else None}
+            cli["agrees"] = bool(m and int(m.group(2)) == n_iter and abs(float(m.group(1)) - logL) <= 1e-6)
+    same = bool(dat["geno"].shape == geno.shape and np.array_equal(dat["ua"], ua) and np.array_equal(dat["geno"], geno))
+    return {"value": n_iter / dt, "ms_per_step": dt * 1e3 / n_iter, "steps": n_iter, "unit": "EM iterations/s",
+            "config": {"workload": "c1: %s, through the STRUCTURE reader" % w["desc"], "I": w["I"], "L": w["L"], "T": int(dat["ua"].sum()),
+                       "ploidy": w["ploidy"], "K": w["K"], "accel_scheme": 0, "max_iter": iters, "logL": logL,
+                       "reader_s": read_s, "reader_returns_the_generated_genotype": same, "command_line": cli}}
 
 
 # ------------------------------------------------------------------------------------------------ c4: initialisations sharded
@@ -890,8 +967,9 @@ def main():
     out, fit, accel = run_single_fit(args, env, name, ua, geno, args.steps, args.warmup)
     if want_cpu:
         attach_cpu_baseline(out, w, ua, geno, accel, args.cpu_budget, env.local_rank, ref_budget_s=args.ref_budget)
-    # the other BASELINE.json configurations on the same line (plain numbers, same measurement rules): configs[1] (c2) at
-    # N = 1; configs[3] (c4: 50 initialisations sharded) at every N; configs[4] (c5: 200 bootstrap replicates sharded) at N > 1
+    # the other BASELINE.json configurations on the same line (plain numbers, same measurement rules): configs[3] (c4: 50
+    # initialisations sharded) and configs[4] (c5: 200 bootstrap replicates sharded) at every N; configs[1] (c2) and configs[0]
+    # (c1, through the STRUCTURE reader) at N = 1
     if name == "c3" and not args.no_secondary:
         sec = {}
         c4 = run_units(env, fit, WORKLOADS["c4"], T, args.units, args.steps, 0, with_roofline=False)
@@ -915,6 +993,14 @@ def main():
             sec["c2"]["roofline"] = roofline_object(ctx2, w2, int(ua2.sum()), w2["K"], c2["value"], "c2", nnz2, 100)
             sec["c2"]["roofline"]["measured_in"] = "a separate batch of 100 EM steps with HIP events around every pass"
             fit2.close()
+            del geno2
+            # configs[4] and configs[0] at N = 1 too: the anchor of c5's strong-scaling curve, and the parity configuration
+            w5 = WORKLOADS["c5"]
+            ua5, geno5 = workload_data(w5, env)
+            c5 = run_bootstrap(env, w5, ua5, geno5, args.replicates, args.steps, n_streams=args.streams)
+            sec["c5"] = dict(c5, unit="EM iterations/s", scaling="strong")
+            del geno5
+            sec["c1"] = run_c1_reader(env)
         else:
             w5 = WORKLOADS["c5"]
             ua5, geno5 = workload_data(w5, env)

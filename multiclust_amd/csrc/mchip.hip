@@ -107,7 +107,15 @@ struct mchip_context {
 	double *d_stage;		/* K*T staging for the [K][T] <-> [T][K] transposes */
 	double *d_logp;			/* mixture model: log P table [T][K] */
 	/* workspaces */
-	int ichunk, n_ichunks, lchunk, n_lchunks, n_llpart, n_ll_col, n_ll_ind, flush_blocks, safe_rcp, sparse;
+	int ichunk, n_ichunks, lchunk, n_lchunks, n_llpart, flush_blocks, safe_rcp, sparse;
+	int ind_waves;			/* waves per workgroup of the cooperating individual-side kernels (mchip_internal.h) */
+	/* testing / tuning knobs of the environment (README), read when a context is created and again with every data set and every
+	 * model -- never on a launch path */
+	struct {
+		int no_bial, no_counts, force_dense, force_safe, no_graph, no_dual, no_slab_sum, no_col_split, part_no_tile, sim_no_tile;
+		int per_cu_col, per_cu_ind, geometry_given;
+		double slab_frac;
+	} knob;
 	double *d_ssum;			/* [I][K] chunk-summed S-side sums */
 	double *d_Apart, *d_Spart, *d_llpart, *d_scalars;	/* d_scalars: [0]=logL, [1..3]=dots, [4..]=eta sums */
 	double *d_llpart2;		/* partial log likelihoods of the second parameter set of a dual individual pass */
@@ -128,6 +136,28 @@ struct mchip_context {
 	std::vector<int> ev_kind;	/* kernel kind of pair p = events 2p, 2p+1 */
 	size_t ev_used;
 };
+
+static void read_knobs(mchip_context *ctx)
+{
+	auto on = [](const char *name) { return getenv(name) != nullptr ? 1 : 0; };
+	auto num = [](const char *name, int dflt) { const char *e = getenv(name); return (e && atoi(e) > 0) ? atoi(e) : dflt; };
+	ctx->knob.no_bial = on("MCHIP_NO_BIAL");
+	ctx->knob.no_counts = on("MCHIP_NO_COUNTS");
+	ctx->knob.force_dense = on("MCHIP_FORCE_DENSE");
+	ctx->knob.force_safe = on("MCHIP_FORCE_SAFE");
+	ctx->knob.no_graph = on("MCHIP_NO_GRAPH");
+	ctx->knob.no_dual = on("MCHIP_NO_DUAL");
+	ctx->knob.no_slab_sum = on("MCHIP_NO_SLAB_SUM");
+	ctx->knob.no_col_split = on("MCHIP_NO_COL_SPLIT");
+	ctx->knob.part_no_tile = on("MCHIP_PART_NO_TILE");
+	ctx->knob.sim_no_tile = on("MCHIP_SIM_NO_TILE");
+	const int both = num("MCHIP_BLOCKS_PER_CU", 64);
+	ctx->knob.per_cu_col = num("MCHIP_BLOCKS_PER_CU_COL", both);
+	ctx->knob.per_cu_ind = num("MCHIP_BLOCKS_PER_CU_IND", both);
+	const char *f = getenv("MCHIP_SLAB_FRAC");
+	ctx->knob.slab_frac = (f && atof(f) > 0) ? atof(f) : 0.3;
+	ctx->knob.geometry_given = on("MCHIP_BLOCKS_PER_CU") || on("MCHIP_BLOCKS_PER_CU_COL") || on("MCHIP_SLAB_FRAC");
+}
 
 static int fail(mchip_context *ctx, int code, const char *fmt, const char *detail)
 {
@@ -1397,7 +1427,9 @@ static mchip_pass_args pass_args(mchip_context *ctx, int slot)
 	a.lchunk = ctx->lchunk; a.n_lchunks = ctx->n_lchunks; a.Spart = ctx->d_Spart;
 	a.asA = ctx->d_asA; a.asS = ctx->d_asS;
 	a.sparse = ctx->sparse; a.tile_cols = 8 * ctx->max_M;
-	a.biallelic = (ctx->min_M == 2 && ctx->max_M == 2 && !getenv("MCHIP_NO_BIAL")) ? 1 : 0;
+	a.biallelic = (ctx->min_M == 2 && ctx->max_M == 2 && !ctx->knob.no_bial) ? 1 : 0;
+	a.ind_waves = ctx->ind_waves;
+	a.no_col_split = ctx->knob.no_col_split;
 	return a;
 }
 
@@ -1432,6 +1464,8 @@ int mchip_create(mchip_context **out, int device)
 	ctx->first_empty = -1;
 	ctx->device = device;
 	ctx->err[0] = 0;
+	ctx->ind_waves = 1;
+	read_knobs(ctx);
 	if (MCHIP_WAIT(hipSetDevice(device)) != hipSuccess || MCHIP_WAIT(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
 		delete ctx;
 		return MCHIP_ERR_HIP;
@@ -1509,6 +1543,7 @@ static int set_shape_impl(mchip_context *ctx, int I, int L, int ploidy, const in
 {
 	if (I <= 0 || L <= 0 || ploidy <= 0 || ploidy > 64 || !ua)
 		return fail(ctx, MCHIP_ERR_INVALID, "set_genotypes: bad shape or null pointer%s", nullptr);
+	read_knobs(ctx);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	/* The same shape and allele lists as the data set held (the next bootstrap replicate, a re-upload): every buffer stays;
@@ -1583,7 +1618,7 @@ static int install_layouts(mchip_context *ctx, int has_missing)
 	ctx->has_missing = has_missing;
 	ctx->counts_valid = 0;	/* counted when asked for (mchip_data_counts): a bootstrap replicate never asks */
 	ctx->count_bits = ploidy <= 3 ? 2 : (ploidy <= 15 ? 4 : 0);
-	if (getenv("MCHIP_NO_COUNTS")) ctx->count_bits = 0;
+	if (ctx->knob.no_counts) ctx->count_bits = 0;
 	if (ctx->count_bits) {
 		const int G = 128 / ctx->count_bits;
 		const size_t nwords = (size_t)((I + G - 1) / G) * T;
@@ -1773,6 +1808,7 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	/* the element-per-thread kernels over parameters take one work-item per entry of P or Q */
 	if ((size_t)K * ctx->T >= ((size_t)1 << 31) || (size_t)K * ctx->I >= ((size_t)1 << 31))
 		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "K*T or K*I of 2^31 or more is not supported%s", nullptr);
+	read_knobs(ctx);
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	{	/* the buffers of this very model are still allocated (same data shape, same arguments): zero the parameters and go */
@@ -1829,15 +1865,11 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	 * config 3 reaches its 64 workgroups per CU before either cap).  The column pass stops at 15 % once the grid fills the
 	 * device twice over: its slabs are K*T doubles each and k_finalize_p reads them all (config 5: 28 -> 15 slabs, 1.61 ->
 	 * 1.56 ms per step; scripts/diag/geom.sh).  Chunk sizes are multiples of 8. */
-	int per_cu_col = 64, per_cu_ind = 64;
-	if (const char *e = getenv("MCHIP_BLOCKS_PER_CU")) per_cu_col = per_cu_ind = atoi(e) > 0 ? atoi(e) : 64;	/* tuning knobs */
-	if (const char *e = getenv("MCHIP_BLOCKS_PER_CU_COL")) per_cu_col = atoi(e) > 0 ? atoi(e) : per_cu_col;
-	if (const char *e = getenv("MCHIP_BLOCKS_PER_CU_IND")) per_cu_ind = atoi(e) > 0 ? atoi(e) : per_cu_ind;
+	const int per_cu_col = ctx->knob.per_cu_col, per_cu_ind = ctx->knob.per_cu_ind;	/* tuning knobs (default 64) */
 	int target = per_cu_col * ctx->n_cu;
 	const int col_tiles = (ctx->T + MCHIP_BLOCK - 1) / MCHIP_BLOCK;
 	const int iblocks = (ctx->I + 7) / 8, lblocks = (ctx->L + 7) / 8;
-	double slab_frac = 0.3;
-	if (const char *e = getenv("MCHIP_SLAB_FRAC")) slab_frac = atof(e) > 0 ? atof(e) : slab_frac;	/* tuning knob */
+	const double slab_frac = ctx->knob.slab_frac;	/* tuning knob (default 0.3) */
 	/* column pass: slab bytes per chunk 8*K*T, genotype bytes per chunk ichunk*L*ploidy */
 	int min_ichunk = (int)ceil(8.0 * K * ctx->T / (slab_frac * ctx->L * ctx->ploidy));
 	int want = (target + col_tiles - 1) / col_tiles;
@@ -1846,11 +1878,15 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 		const int cap_lo = cap / 2;						/* half the slab budget */
 		const int fill = (2 * 8 * ctx->n_cu + col_tiles - 1) / col_tiles;	/* two rounds of 8 resident workgroups per CU */
 		const int soft = cap_lo > (fill < cap ? fill : cap) ? cap_lo : (fill < cap ? fill : cap);
-		if (!getenv("MCHIP_BLOCKS_PER_CU") && !getenv("MCHIP_BLOCKS_PER_CU_COL") && !getenv("MCHIP_SLAB_FRAC") && want > soft) want = soft;
+		if (!ctx->knob.geometry_given && want > soft) want = soft;
 	}
 	if (want > cap) want = cap;
 	if (want < 1) want = 1;
 	if (want > iblocks) want = iblocks;
+	if (ctx->count_bits) {	/* the packed-count column pass puts MCHIP_COL_WAVES chunks into a workgroup: whole workgroups where the caps allow */
+		const int up = ((want + MCHIP_COL_WAVES - 1) / MCHIP_COL_WAVES) * MCHIP_COL_WAVES;
+		if (up <= cap && up <= iblocks) want = up;
+	}
 	{
 		const int gran = ctx->count_bits ? 128 / ctx->count_bits : 8;	/* individuals per packed word */
 		const int per = (ctx->I + want - 1) / want;
@@ -1868,16 +1904,26 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	if (want > cap) want = cap;
 	if (want < 1) want = 1;
 	if (want > lblocks) want = lblocks;
-	ctx->lchunk = ((lblocks + want - 1) / want) * 8;
-	ctx->n_lchunks = (ctx->L + ctx->lchunk - 1) / ctx->lchunk;
-	ctx->n_ll_col = col_tiles * ctx->n_ichunks;
-	ctx->n_ll_ind = ind_tiles * ctx->n_lchunks;
 	{	/* the sparse individual pass stages two tiles of 8 loci of P rows in LDS: use it while they fit 64 KiB */
 		const size_t kp = (size_t)mchip_kp(K);
 		const size_t lds = (2 * 8 * (size_t)ctx->max_M * kp + mchip_qblock(K)) * sizeof(double);
-		ctx->sparse = (ctx->max_M <= MCHIP_SPARSE_MAX_M) && lds <= 65536 && !getenv("MCHIP_FORCE_DENSE");
+		ctx->sparse = (ctx->max_M <= MCHIP_SPARSE_MAX_M) && lds <= 65536 && !ctx->knob.force_dense;
 	}
-	ctx->n_llpart = ctx->n_ll_col > ctx->n_ll_ind ? ctx->n_ll_col : ctx->n_ll_ind;
+	/* cooperating waves (mchip_internal.h): chunks are still what ONE WAVE takes; a workgroup of the sparse individual-side kernels
+	 * is ind_waves of them, so a whole number of workgroups wants a multiple of that many chunks where the caps allow it */
+	ctx->ind_waves = (admixture && ctx->sparse && mchip_ind_split(K) == 1) ? mchip_ind_waves(K, 8 * ctx->max_M) : 1;
+	if (ctx->ind_waves > 1) {
+		const int up = ((want + ctx->ind_waves - 1) / ctx->ind_waves) * ctx->ind_waves;
+		if (up <= cap && up <= lblocks) want = up;
+	}
+	ctx->lchunk = ((lblocks + want - 1) / want) * 8;
+	ctx->n_lchunks = (ctx->L + ctx->lchunk - 1) / ctx->lchunk;
+	{	/* partial log likelihoods any pass can leave: one per workgroup; no individual-side kernel has fewer than 64 individuals
+		 * per workgroup, no column-side one fewer than 64 columns */
+		const int by_col = ((ctx->T + 63) / 64) * ctx->n_ichunks, by_ind = ((ctx->I + 63) / 64) * ctx->n_lchunks;
+		(void)col_tiles; (void)ind_tiles;
+		ctx->n_llpart = by_col > by_ind ? by_col : by_ind;
+	}
 	HIPCHK(hipMalloc((void **)&ctx->d_Apart, (size_t)ctx->n_ichunks * KT * sizeof(double)));
 	HIPCHK(hipMalloc((void **)&ctx->d_Spart, (size_t)ctx->n_lchunks * ctx->I * K * sizeof(double)));
 	HIPCHK(hipMalloc((void **)&ctx->d_llpart, (size_t)ctx->n_llpart * sizeof(double)));
@@ -1907,7 +1953,7 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 		 * kernels take one reciprocal per non-empty cell and zero-count cells contribute exactly 0, as in em_alg.c:338-342.
 		 * A non-empty cell with t = 0 is NaN here as it is in the reference (n * 0 / 0). */
 		ctx->safe_rcp = (!do_projection || !(p_lb >= 1e-75)) ? 1 : 0;
-		if (getenv("MCHIP_FORCE_SAFE")) ctx->safe_rcp = 1;
+		if (ctx->knob.force_safe) ctx->safe_rcp = 1;
 		if (ctx->safe_rcp) ctx->flush_blocks = 0;
 	}
 	HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2047,7 +2093,7 @@ static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int m
 		ctx->kt->mix_column(b, ctx->stream);
 		prof_mark(ctx, MCHIP_KERN_ACCUM_P, false);
 		hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
-				   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
+				   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->kt->col_slabs(b, 1), ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
 				   0, ctx->p_lb, ctx->do_projection, ctx->p_lb, ctx->d_flags, stop);
 	}
 	HIPCHK(hipGetLastError());
@@ -2076,19 +2122,20 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 		prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
 		ctx->kt->accum_q(a, ctx->stream);
 		prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
-		ctx->ll_parts = ctx->sparse ? ctx->n_ll_ind : ctx->n_ll_col;
+		ctx->ll_parts = ctx->kt->ind_ll_parts(a);
 		if (!defer_ll)
 			hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->ll_parts, ctx->d_scalars, stop);
 	}
 	ctx->s_cache_slot = -1;		/* Spart is consumed below; slot `to` is about to change */
 	const int indiv = ctx->qstride != 0;
-	if (ctx->n_lchunks <= 16) {
+	const int s_slabs = ctx->kt->ind_slabs(a), n_slabs = ctx->kt->col_slabs(a, 0);	/* what the passes above left (cooperating waves: a quarter) */
+	if (s_slabs <= 16) {
 		/* few slabs (small data sets, where a launch costs as much as the work): k_finalize_q adds them itself, in slab order */
-		ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[from], ctx->qstride,
+		ctx->kt->finalize_q(ctx->I, ctx->K, s_slabs, ctx->d_Spart, ctx->d_q[from], ctx->qstride,
 				    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream, 0.0);
 	} else {
 		const size_t n = (size_t)ctx->I * ctx->K;
-		hipLaunchKernelGGL(k_sum_slabs, dim3(nblk(n, 32)), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_Spart, ctx->n_lchunks, n, ctx->d_ssum, stop);
+		hipLaunchKernelGGL(k_sum_slabs, dim3(nblk(n, 32)), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_Spart, s_slabs, n, ctx->d_ssum, stop);
 		ctx->kt->finalize_q(ctx->I, ctx->K, 1, ctx->d_ssum, ctx->d_q[from], ctx->qstride,
 				    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream, 0.0);
 	}
@@ -2098,17 +2145,17 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 			int rc = finalize_shared_eta(ctx, to, stop);
 			if (rc) return rc;
 		}
-		if (ctx->n_ichunks > 8 && !getenv("MCHIP_NO_SLAB_SUM")) {
+		if (n_slabs > 8 && !ctx->knob.no_slab_sum) {
 			/* many N-side slabs: k_sum_slabs adds them at 5 TB/s (element- and slab-level parallelism, fully coalesced; the
 			 * (l, k) threads of k_finalize_p reach 2.7 TB/s on the same bytes), k_finalize_p then reads one slab */
 			const size_t n = (size_t)ctx->K * ctx->T;
-			hipLaunchKernelGGL(k_sum_slabs, dim3(nblk(n, 32)), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_Apart, ctx->n_ichunks, n, ctx->d_stage, stop);
+			hipLaunchKernelGGL(k_sum_slabs, dim3(nblk(n, 32)), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_Apart, n_slabs, n, ctx->d_stage, stop);
 			hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
 					   ctx->L, ctx->K, ctx->T, ctx->d_toff, 1, ctx->d_stage, ctx->d_p[from], ctx->d_p[to],
 					   1, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags, stop);
 		} else {
 			hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
-					   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->n_ichunks, ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
+					   ctx->L, ctx->K, ctx->T, ctx->d_toff, n_slabs, ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
 					   1, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags, stop);
 		}
 	}
@@ -2130,7 +2177,7 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
 	/* The step is a launch-bound chain of 6-7 kernels on small data sets: capture it once into a hipGraph and replay it
 	 * (eager launches cost ~8 us of host time each here, graph nodes ~1.5 us of device time).  Event marks cannot be
 	 * captured, so profiled runs stay eager. */
-	bool use_graph = !ctx->profiling && n_steps >= 4 && !getenv("MCHIP_NO_GRAPH");
+	bool use_graph = !ctx->profiling && n_steps >= 4 && !ctx->knob.no_graph;
 	if (use_graph && !ctx->step_graph[slot]) {
 		hipGraph_t graph = nullptr;
 		if (MCHIP_WAIT(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal)) == hipSuccess) {
@@ -2206,8 +2253,7 @@ int mchip_loglik(mchip_context *ctx, int slot, double *loglik)
 	prof_mark(ctx, MCHIP_KERN_LOGLIK, true);
 	ctx->kt->loglik(a, ctx->stream);
 	prof_mark(ctx, MCHIP_KERN_LOGLIK, false);
-	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart,
-			   ctx->sparse ? ctx->n_ll_ind : ctx->n_ll_col, ctx->d_scalars + 1);
+	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->kt->ind_ll_parts(a), ctx->d_scalars + 1);
 	HIPCHK(hipGetLastError());
 	if (loglik) return fetch_scalars(ctx, 1, 1, loglik);
 	return MCHIP_OK;
@@ -2224,7 +2270,7 @@ int mchip_loglik_prefetch(mchip_context *ctx, int slot, double *loglik)
 	prof_mark(ctx, MCHIP_KERN_ACCUM_Q, true);
 	ctx->kt->accum_q(a, ctx->stream);		/* S-side sums -> Spart, logL partials -> llpart */
 	prof_mark(ctx, MCHIP_KERN_ACCUM_Q, false);
-	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_ll_ind, ctx->d_scalars + 2);
+	hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->kt->ind_ll_parts(a), ctx->d_scalars + 2);
 	HIPCHK(hipGetLastError());
 	ctx->s_cache_slot = slot;
 	if (loglik) return fetch_scalars(ctx, 2, 1, loglik);
@@ -2419,7 +2465,7 @@ static void mod_k_magic(int K, uint32_t *magic, uint32_t *shift)
 static int rand_partition_tiled(mchip_context *ctx, const uint32_t *window, int to)
 {
 	const int K = ctx->K, KP = (K + 1) & ~1, pl = ctx->ploidy;
-	if (pl > 8 || (size_t)ctx->lchunk * pl > 65535 || getenv("MCHIP_PART_NO_TILE")) return -1;
+	if (pl > 8 || (size_t)ctx->lchunk * pl > 65535 || ctx->knob.part_no_tile) return -1;
 	/* N-side counters of a tile: tile * max_M * KP / 2 words, about 16 KiB, a multiple of 8 loci */
 	int tile = (int)((16384 / ((size_t)ctx->max_M * KP * 2)) & ~(size_t)7);
 	if (tile < 8) tile = 8;
@@ -2592,7 +2638,7 @@ int mchip_simulate_genotypes(mchip_context *ctx, int I, int L, int ploidy, const
 		hipLaunchKernelGGL(k_walk_tables, dim3(nblk(n)), dim3(256), 0, ctx->stream, (int)n_qrows, K, L, ctx->T, ctx->d_toff, d_q.p, d_p.p,
 				   fast, d_cq.p, d_cp.p);
 	}
-	if (fast && ploidy <= 8 && !getenv("MCHIP_SIM_NO_TILE")) {
+	if (fast && ploidy <= 8 && !ctx->knob.sim_no_tile) {
 		/* tile: as many loci as keep the staged thresholds near 16 KiB (three workgroups per compute unit), a multiple of 8 */
 		int tile = (16384 / (K * 12)) & ~7;
 		if (tile > 512) tile = 512;
@@ -2794,7 +2840,7 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 	dual.P2 = ctx->d_p[C];
 	dual.Q2 = ctx->d_q[C];
 	dual.llpart2 = ctx->d_llpart2;
-	const bool use_dual = ctx->admixture && !getenv("MCHIP_NO_DUAL") && ctx->kt->dual_available(dual);
+	const bool use_dual = ctx->admixture && !ctx->knob.no_dual && ctx->kt->dual_available(dual);
 	if (!ctx->admixture) {
 		if ((rc = run_mixture(ctx, C, C, 0, 1, stop, 1))) return rc;	/* logL_mixture */
 	} else if (!use_dual) {
@@ -2803,7 +2849,7 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 		prof_mark(ctx, MCHIP_KERN_LOGLIK, true);
 		ctx->kt->loglik(a, ctx->stream);
 		prof_mark(ctx, MCHIP_KERN_LOGLIK, false);
-		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->n_ll_ind, ctx->d_scalars + 1, stop);
+		hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_llpart, ctx->kt->ind_ll_parts(a), ctx->d_scalars + 1, stop);
 	}
 	/* step size (accel_em.c:130-243) -> d_scalars[24] */
 	{	/* (the secants u = B - A, v = C - B are formed inside the kernels that use them: nothing stores them in a batched cycle) */
@@ -2838,7 +2884,7 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 	/* the two log likelihoods' sums and accept iff ll > emll, one launch; the outcome goes back to slot A */
 	if (ctx->admixture)
 		hipLaunchKernelGGL(k_reduce_accept, dim3(1), dim3(MCHIP_BLOCK), 0, ctx->stream, use_dual ? ctx->d_llpart2 : (const double *)nullptr, ctx->d_llpart,
-				   ctx->n_ll_ind, ctx->d_scalars, cyc, stop);
+				   ctx->kt->ind_ll_parts(dual), ctx->d_scalars, cyc, stop);
 	else
 		hipLaunchKernelGGL(k_accept, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scalars, cyc, stop);
 	hipLaunchKernelGGL(k_select_copy, dim3(nblk(nq + KT)), dim3(256), 0, ctx->stream, ctx->d_q[A], ctx->d_q[B], ctx->d_q[C], nq,
@@ -2864,7 +2910,7 @@ int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchi
 	HIPCHK(hipMemcpyAsync(ctx->d_cyc, cyc0, sizeof cyc0, hipMemcpyHostToDevice, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));	/* cyc0 is a stack array */
 	ctx->s_cache_slot = -1;
-	bool use_graph = !ctx->profiling && !getenv("MCHIP_NO_GRAPH");
+	bool use_graph = !ctx->profiling && !ctx->knob.no_graph;
 	hipGraphExec_t &exec = ctx->cycle_graph[slot][scheme];
 	if (use_graph && !exec) {
 		hipGraph_t graph = nullptr;

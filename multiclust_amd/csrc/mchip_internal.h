@@ -87,6 +87,20 @@ constexpr int mchip_kp(int K)
 	return base + ((base % 16 == 0) ? 2 : 0);
 }
 
+/* Cooperating waves (round 4).  Both streaming passes reduce thread-privately over a chunk of the other axis and leave one slab
+ * of partial sums per chunk; the slabs cost HBM traffic twice (written, then added up) and were 131 MB (S side, 205 slabs) and
+ * 269 MB (N side, 14 slabs) per EM step at config 3.  The waves of a workgroup now take the SAME lanes' worth of individuals
+ * (columns) and consecutive sub-chunks of loci (individuals), and add their sums through LDS in wave order before one of them
+ * stores the slab: as many waves and as much work per wave as before, a quarter of the slabs.  For the sparse individual pass
+ * this also makes the staged P tile private to a wave (each wave is at other loci): no workgroup barrier inside the loop. */
+constexpr int MCHIP_COL_WAVES = MCHIP_BLOCK / 64;	/* column pass on packed counts: waves per workgroup = sub-chunks per slab */
+#ifndef MCHIP_IND_WAVES_MAX
+#define MCHIP_IND_WAVES_MAX 4
+#endif
+/* sparse individual pass: waves per workgroup, each with its own double-buffered tile of tile_cols staged rows (two such
+ * pairs where the dual pass exists, K <= 12): the largest of 4, 2, 1 whose tiles fit 48 KiB */
+inline int mchip_ind_waves(int K, int tile_cols);
+
 enum { MCHIP_KERN_ACCUM_P = 0, MCHIP_KERN_ACCUM_Q = 1, MCHIP_KERN_LOGLIK = 2, MCHIP_KERN_DUAL = 3, MCHIP_KERN_COUNT = 4 };
 
 /* arguments of the two streaming passes over the genotype matrix */
@@ -110,6 +124,9 @@ struct mchip_pass_args {
 	/* individual pass (lane = individual, loop over a chunk of loci) */
 	int lchunk, n_lchunks;	/* loci per chunk (multiple of 8) */
 	double *Spart;		/* [n_lchunks][I][K] sum_c P_kc r_ic over the chunk */
+	int no_col_split;	/* MCHIP_NO_COL_SPLIT (experiments): one lane per allele column at every K */
+	int ind_waves;		/* sparse / biallelic individual passes: waves per workgroup; wave w takes sub-chunk w of lchunk loci of the
+				 * workgroup's ind_waves * lchunk loci, the slab index is blockIdx.y (mchip_ind_slabs() of them) */
 	/* sparse individual pass: P rows of 8 loci staged in LDS */
 	int sparse;		/* 1: sparse individual pass + N-only column pass; 0: dense pair */
 	int tile_cols;		/* LDS tile capacity in allele columns (8 * max alleles per locus) */
@@ -148,8 +165,24 @@ struct mchip_ktable {
 	/* individual pass of (a.Q, a.P) that also takes log L of (a.Q2, a.P2) into a.llpart2, where dual_available() says so */
 	int (*dual_available)(const mchip_pass_args &a);
 	void (*accum_q_dual)(const mchip_pass_args &a, hipStream_t s);
+	/* what the launchers above will leave for these arguments: N-side slabs of accum_p (mix = 0) / mix_column (mix = 1); S-side
+	 * slabs of accum_q / accum_q_dual (= of loglik's partial sums), and partial log likelihoods of accum_q / loglik */
+	int (*col_slabs)(const mchip_pass_args &a, int mix);
+	int (*ind_slabs)(const mchip_pass_args &a);
+	int (*ind_ll_parts)(const mchip_pass_args &a);
 };
 
 const mchip_ktable *mchip_get_ktable(int K);
+
+inline int mchip_ind_waves(int K, int tile_cols)
+{
+	const size_t per_wave = (size_t)(K <= 12 ? 4 : 2) * (size_t)tile_cols * (size_t)mchip_kp(K) * sizeof(double);
+	for (int w = MCHIP_IND_WAVES_MAX; w > 1; w >>= 1)
+		if ((size_t)w * per_wave <= 48 * 1024) return w;
+	return 1;
+}
+/* slabs (and partial log likelihoods per individual tile) the cooperating forms of the passes leave */
+inline int mchip_ind_slabs(const mchip_pass_args &a) { return (a.n_lchunks + a.ind_waves - 1) / a.ind_waves; }
+inline int mchip_col_slabs(const mchip_pass_args &a) { return (a.n_ichunks + MCHIP_COL_WAVES - 1) / MCHIP_COL_WAVES; }
 
 #endif

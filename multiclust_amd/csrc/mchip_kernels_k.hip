@@ -79,6 +79,10 @@ template <> struct geno_group<2> {
 		return (int)((w & 0xFFu) == m) + (int)((w >> 8) == m);
 	}
 	__device__ __forceinline__ unsigned copy(int j, int a, int) const { return (field(j) >> (8 * a)) & 0xFFu; }
+	/* the loaded word is here from now on (an empty statement that reads it: hipcc puts its s_waitcnt in front of it).  Before
+	 * a loop whose body starts with loads of its own: the in-order counter would otherwise make the body's first use of this
+	 * group wait for those younger loads as well, every trip */
+	__device__ __forceinline__ void arrive() const { asm volatile("" :: "v"(g.x), "v"(g.y), "v"(g.z), "v"(g.w)); }
 	/* entries 4h..4h+3 moved to positions 0..3 (h wave-uniform) */
 	__device__ __forceinline__ geno_group<2> half(int h) const
 	{
@@ -110,6 +114,10 @@ template <> struct geno_group<4> {	/* tetraploid: 8 entries x 4 bytes = two 16-b
 		return (int)((w & 0xFFu) == m) + (int)(((w >> 8) & 0xFFu) == m) + (int)(((w >> 16) & 0xFFu) == m) + (int)((w >> 24) == m);
 	}
 	__device__ __forceinline__ unsigned copy(int j, int a, int) const { return (field(j) >> (8 * a)) & 0xFFu; }
+	__device__ __forceinline__ void arrive() const
+	{
+		asm volatile("" :: "v"(g0.x), "v"(g0.y), "v"(g0.z), "v"(g0.w), "v"(g1.x), "v"(g1.y), "v"(g1.z), "v"(g1.w));
+	}
 	__device__ __forceinline__ geno_group<4> half(int h) const
 	{
 		geno_group<4> r;
@@ -129,6 +137,7 @@ template <> struct geno_group<0> {	/* any ploidy: byte loads */
 		return n;
 	}
 	__device__ __forceinline__ unsigned copy(int j, int a, int pl) const { return p[j * pl + a]; }
+	__device__ __forceinline__ void arrive() const {}	/* (bytes are loaded where they are used) */
 	__device__ __forceinline__ geno_group<0> half(int h) const
 	{
 		geno_group<0> r;
@@ -261,7 +270,11 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 	constexpr unsigned MASK = (1u << BITS) - 1u;
 	/* individuals per inner step: their q rows must fit the scalar register file (2K SGPRs each, about 100 usable) */
 	constexpr int NJ = K <= 12 ? 4 : (K <= 20 ? 2 : 1);
-	const int c_raw = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
+	/* the workgroup's MCHIP_COL_WAVES waves take the same 64 allele columns and consecutive sub-chunks of a.ichunk individuals;
+	 * their sums meet in LDS below, in wave order, and wave 0 stores the slab (mchip_internal.h: cooperating waves) */
+	__shared__ double wsum[K][64];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;	/* wv is wave-uniform */
+	const int c_raw = blockIdx.x * 64 + lane;
 	const bool valid = c_raw < a.T;
 	const int c = valid ? c_raw : a.T - 1;
 	double p[K], acc[K];
@@ -270,11 +283,11 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 		p[k] = MIX ? 0.0 : a.P[(size_t)c * K + k];
 		acc[k] = 0.0;
 	}
-	const int i0 = blockIdx.y * a.ichunk;		/* multiple of G */
+	const int i0 = __builtin_amdgcn_readfirstlane((blockIdx.y * MCHIP_COL_WAVES + wv) * a.ichunk);	/* multiple of G */
 	const int i1 = min(a.I, i0 + a.ichunk);
-	const int g_end = (i1 + G - 1) / G;
+	const int g_end = (i1 + G - 1) / G;		/* (a wave whose sub-chunk starts behind the last individual has no groups) */
 	const uint4 *gt = reinterpret_cast<const uint4 *>(a.gtC);
-	uint4 w = gt[(size_t)(i0 / G) * a.T + c];
+	uint4 w = gt[(size_t)min(i0 / G, (a.I - 1) / G) * a.T + c];
 	for (int g = i0 / G; g < g_end; g++) {
 		const uint4 wn = gt[(size_t)min(g + 1, g_end - 1) * a.T + c];	/* prefetch (clamped) */
 #pragma unroll 1
@@ -320,8 +333,26 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 		}
 		w = wn;
 	}
-	if (valid) {
-		double *out = a.Apart + ((size_t)blockIdx.y * a.T + c) * K;
+	/* (lane, wave and column are worked out again from the thread index, laundered so that hipcc does not keep the first copies
+	 * alive across the loop: those four registers were the difference between 7 and 6 waves per SIMD at K = 8) */
+	unsigned tid = threadIdx.x;
+	asm volatile("" : "+v"(tid));
+	const int lane2 = (int)(tid & 63u), wv2 = (int)(tid >> 6);
+	for (int x = 1; x < MCHIP_COL_WAVES; x++) {	/* wave x hands its sums to wave 0: one wave's worth of LDS, taken in turns */
+		if (wv2 == x) {
+#pragma unroll
+			for (int k = 0; k < K; k++) wsum[k][lane2] = acc[k];
+		}
+		__syncthreads();
+		if (wv2 == 0) {
+#pragma unroll
+			for (int k = 0; k < K; k++) acc[k] += wsum[k][lane2];
+		}
+		__syncthreads();
+	}
+	const int c2 = (int)blockIdx.x * 64 + lane2;
+	if (wv2 == 0 && c2 < a.T) {
+		double *out = a.Apart + ((size_t)blockIdx.y * a.T + c2) * K;
 #pragma unroll
 		for (int k = 0; k < K; k++) out[k] = acc[k];
 	}
@@ -860,6 +891,349 @@ __global__ __launch_bounds__(QBLOCK, sparse_min_waves(PL, ACCUM)) void k_individ
 	}
 }
 
+/* ---------------------------------------------------------------- individual pass, sparse form, cooperating waves (K <= 27)
+ * The same lane arithmetic as k_individual_sparse above (which stays for the lane-split K >= 28, whose tiles are too large to be
+ * private), another division of labour: a workgroup is a.ind_waves waves over the SAME 64 individuals; wave w takes sub-chunk w
+ * (a.lchunk loci) of the workgroup's a.ind_waves * a.lchunk loci, with its OWN double-buffered tile of staged P rows -- the waves
+ * of a workgroup are at different loci, nothing in the loop is shared, and there is no workgroup barrier in it; they drift apart
+ * and cover each other's block heads.  After the loop the waves hand their sums to wave 0 through LDS, in wave order, and wave 0
+ * stores ONE slab of S-side sums and one partial log likelihood: a quarter of the slab traffic of one slab per wave pair
+ * (mchip_internal.h: cooperating waves). */
+__device__ __forceinline__ double wave_total(double v)
+{
+	/* fixed tree over the 64 lanes; lane 0 ends with the total */
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+	return v;
+}
+
+constexpr int WSTAGE = 4;	/* doubles of the next tile a lane keeps in registers: tiles of up to 256 doubles (32 columns at K = 8) */
+/* Where a staged row is exactly the K doubles of a P row (KP == K: even K that is no multiple of 16) a tile is a contiguous copy
+ * of P[c_lo .. c_hi) and goes from memory straight into LDS (global_load_lds_dwordx4: 64 lanes x 16 bytes per instruction, LDS
+ * address = M0 + 16 * lane), with no staging registers, no ds_write and no address arithmetic per element.  The statement is
+ * opaque to hipcc: an LDS-DMA it knew about would be waited for in front of the first LDS read that may alias it -- both
+ * buffers live in one dynamic array, so that is the block's first gather -- which is the exposed latency the register
+ * staging exists to avoid.  The wave waits for its copies itself, once, at the end of the block (s_waitcnt vmcnt(0)). */
+#ifdef MCHIP_NO_GLDS
+constexpr bool GLDS = false;
+#else
+constexpr bool GLDS = (KP == K) && (K % 2 == 0) && SPLIT == 1;
+#endif
+/* LDS doubles from one tile buffer to the next: with the direct copy a buffer is written in whole 1 KiB pieces */
+__device__ __host__ __forceinline__ constexpr size_t tile_stride(int tile_cols)
+{
+	return GLDS ? (((size_t)tile_cols * KP + 127) / 128) * 128 : (size_t)tile_cols * KP;
+}
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __forceinline__ void glds_copy(const double *src, lds_double *dst, int nel, int lane)
+{
+	/* nel doubles (even; src 16-byte aligned) to dst[0 .. nel); lanes past the end re-read the last 16 bytes into slots of the
+	 * buffer's padding.  No "memory" clobber: it would cover toff[] / Q / P too, and hipcc then reads those through the vector
+	 * memory path with a wait at the head of every block instead of through the scalar cache (seen in the ISA); the AMDGPU
+	 * backend takes no "m" operands either.  The statements are volatile (kept, and in order among themselves and the wait);
+	 * what the compiler has to know about memory it is told by the fence in glds_wait */
+	const int units = nel >> 1;
+	for (int u0 = 0; u0 < units; u0 += 64) {
+		const double *g = src + 2 * (size_t)min(u0 + lane, units - 1);
+		const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(dst + 2 * (size_t)u0));
+		unsigned keep;
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+			     : "=&s"(keep) : "v"(g), "s"(l));
+	}
+}
+/* the wave's copies have landed; the fence (wavefront scope: no instruction) keeps every later LDS read behind this point and
+ * tells the optimiser that LDS may have changed */
+__device__ __forceinline__ void glds_wait()
+{
+	asm volatile("s_waitcnt vmcnt(0)");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int PL, bool ACCUM, bool SAFE, bool NOMISS, bool DUAL = false>
+__global__ __launch_bounds__(64 * MCHIP_IND_WAVES_MAX) void k_individual_sparse_w(mchip_pass_args a)
+{
+	static_assert(SPLIT == 1, "wave-private tiles: one lane per individual");
+	static_assert(!DUAL || (ACCUM && !SAFE && PL == 2), "dual pass: ACCUM, shared reciprocals, diploid");
+	if (a.stop && *a.stop) return;		/* batched run already stopped (uniform over the grid) */
+	if (ACCUM && !DUAL && a.skip_ind && *a.skip_ind) return;	/* sums + logL partials of these parameters are already there */
+	extern __shared__ __attribute__((aligned(16))) double lds[];	/* [wave][buffer][set][tile_cols][KP]; after the loop: [K + 2][64] hand-over */
+	constexpr int SETS = DUAL ? 2 : 1;
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int W = a.ind_waves;
+	const size_t tile_doubles = tile_stride(a.tile_cols);
+	double *mine = lds + (size_t)wv * 2 * SETS * tile_doubles;
+	const int i_raw = blockIdx.x * 64 + lane;
+	const bool active = i_raw < a.I;
+	const int i = active ? i_raw : a.I - 1;
+	const int pl = PL ? PL : a.ploidy;
+	double q[K], acc[K], q2[DUAL ? K : 1];
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+		q[k] = a.Q[(size_t)i * a.qstride + k];
+		acc[k] = 0.0;
+		if constexpr (DUAL) q2[k] = a.Q2[(size_t)i * a.qstride + k];
+	}
+	const int l0 = (blockIdx.y * W + wv) * a.lchunk;
+	const int l1 = min(a.L, l0 + a.lchunk);
+	double prod = 1.0, prod2 = 1.0;
+	int blk = 0, ex = 0, ex2 = 0;
+	if (l0 < a.L) {		/* (wave-uniform; the last workgroup's trailing waves may have nothing) */
+		if constexpr (!NOMISS) {
+			/* a missing copy borrows column 0 of its locus and multiplies it by r = 0; at a locus WITHOUT any allele column (every
+			 * individual missing: uniquealleles = 0, golden allmiss_*) that row is the next locus's, or, behind the tile's last
+			 * column, whatever the previous kernel left in LDS -- 0 x NaN.  Once per wave: every slot of its tiles is finite */
+			for (size_t x = lane; x < 2 * SETS * tile_doubles; x += 64) mine[x] = 0.0;
+		}
+		const int lb0 = l0 >> 3, lb_end = (l1 + 7) >> 3;
+		const bool staged = a.tile_cols * K <= WSTAGE * 64;	/* wave-uniform */
+		/* column offsets of the current block's and the next block's loci: E[x] = toff[8 lb + x], x = 0..16 (toff is padded by 24
+		 * entries equal to T); the upper half for the NEXT block is requested at the head of this one and moved in at its end */
+		/* (read through the constant address space: toff[] does not change while a kernel runs, and the copy statements above are
+		 * opaque to hipcc -- it would otherwise assume they may have written it and re-read it through the vector memory path) */
+		const __attribute__((address_space(4))) int *toffc = (const __attribute__((address_space(4))) int *)a.toff;
+		int E[17];
+#pragma unroll
+		for (int x = 0; x < 17; x++) E[x] = toffc[lb0 * 8 + x];
+		{	/* stage the first tile */
+			const int c_lo = E[0], c_hi = E[8];
+			const int nel = (c_hi - c_lo) * K;
+			for (int x = lane; x < nel; x += 64) {
+				mine[(x / K) * KP + (x % K)] = a.P[(size_t)c_lo * K + x];
+				if (DUAL) mine[2 * tile_doubles + (x / K) * KP + (x % K)] = a.P2[(size_t)c_lo * K + x];
+			}
+		}
+		geno_group<PL> g, gn;
+		g.load(a.gtS, (size_t)lb0 * a.I + i, pl);
+		g.arrive();
+		for (int lb = lb0; lb < lb_end; lb++) {
+			const int buf = (lb - lb0) & 1;
+			const double *tile = mine + (size_t)buf * tile_doubles;
+			const double *tile2 = mine + (size_t)(2 + buf) * tile_doubles;
+			const int c_lo = E[0];
+			int En[8];
+#pragma unroll
+			for (int x = 0; x < 8; x++) En[x] = toffc[(lb + 1) * 8 + 9 + x];
+			/* the next tile: requested now; tiles of up to WSTAGE * 64 doubles wait in registers while this block is computed and go
+			 * to the wave's other buffer after it (no s_waitcnt for them in front of the arithmetic); larger ones are copied through */
+			double stage[WSTAGE], stage2[DUAL ? WSTAGE : 1];
+			int nel_next = 0;
+			double *dst = mine + (size_t)(buf ^ 1) * tile_doubles;
+			double *dst2 = mine + (size_t)(2 + (buf ^ 1)) * tile_doubles;
+			if (lb + 1 < lb_end) {
+				const int n_lo = E[8], n_hi = E[16];
+				nel_next = (n_hi - n_lo) * K;
+				const double *src = a.P + (size_t)n_lo * K;
+				const double *src2 = DUAL ? a.P2 + (size_t)n_lo * K : nullptr;
+				if constexpr (GLDS) {
+					if (nel_next > 0) {
+						glds_copy(src, (lds_double *)dst, nel_next, lane);
+						if constexpr (DUAL) glds_copy(src2, (lds_double *)dst2, nel_next, lane);
+					}
+				} else if (staged) {
+#pragma unroll
+					for (int s2 = 0; s2 < WSTAGE; s2++) {
+						const int x = lane + s2 * 64;
+						stage[s2] = src[min(x, nel_next - 1)];
+						if constexpr (DUAL) stage2[s2] = src2[min(x, nel_next - 1)];
+					}
+				} else {
+					for (int x = lane; x < nel_next; x += 64) {
+						dst[(x / K) * KP + (x % K)] = src[x];
+						if (DUAL) dst2[(x / K) * KP + (x % K)] = src2[x];
+					}
+				}
+			}
+			gn.load(a.gtS, (size_t)min(lb + 1, lb_end - 1) * a.I + i, pl);
+			int tb[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) tb[j] = E[j];
+			auto one_locus = [&](int j) __attribute__((always_inline)) {
+				const int base = tb[j] - c_lo;
+				if constexpr (PL == 2 || PL == 4) {
+					/* all copies of the locus first (t), then one shared reciprocal for each pair of copies */
+					double pc[PL ? PL : 1][KP], t[PL ? PL : 1];
+					bool miss[PL ? PL : 1];
+					unsigned row[PL ? PL : 1];
+#pragma unroll
+					for (int b = 0; b < PL; b++) {
+						const unsigned mraw = g.copy(j, b, pl);
+						/* NOMISS: the data set has no missing copy: no selects (idle lanes duplicate individual I-1) */
+						miss[b] = NOMISS ? false : ((mraw == MCHIP_MISSING) || !active);
+						const unsigned mm = miss[b] ? 0u : mraw;
+						row[b] = (unsigned)base + mm;
+						/* 16-byte LDS reads (ds_read_b128): twice the bytes per LDS cycle of ds_read2_b64 */
+						const double2 *pr = reinterpret_cast<const double2 *>(tile + (size_t)(base + (int)mm) * KP);
+#pragma unroll
+						for (int k = 0; k < KP / 2; k++) {
+							const double2 v = pr[k];
+							pc[b][2 * k] = v.x;
+							pc[b][2 * k + 1] = v.y;
+						}
+						t[b] = q[0] * pc[b][0];
+#pragma unroll
+						for (int k = 1; k < K; k++) t[b] = __builtin_fma(q[k], pc[b][k], t[b]);
+						/* a missing copy borrowed column 0 of its locus; it takes t = 1 so that it leaves the log-product and
+						 * its partner's shared reciprocal alone, whatever column 0 holds */
+						if (!NOMISS) t[b] = miss[b] ? 1.0 : t[b];
+					}
+					if constexpr (PL == 4 && !SAFE && ACCUM) {
+						/* tetraploid: the four copies of the locus share one reciprocal (rcp4's scheme) */
+						const double p01 = t[0] * t[1], p23 = t[2] * t[3];
+						const double rp = rcp_full(p01 * p23);
+						const double r01 = rp * p23, r23 = rp * p01;
+						const double r[4] = { miss[0] ? 0.0 : r01 * t[1], miss[1] ? 0.0 : r01 * t[0],
+								      miss[2] ? 0.0 : r23 * t[3], miss[3] ? 0.0 : r23 * t[2] };
+#pragma unroll
+						for (int b = 0; b < 4; b++)
+#pragma unroll
+							for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b][k], r[b], acc[k]);
+						prod *= p01;
+						prod *= p23;
+					} else
+#pragma unroll
+					for (int b = 0; b < PL; b += 2) {
+						const double pp = t[b] * t[b + 1];
+						if (ACCUM) {
+							double r0, r1;
+							if (SAFE) {	/* tiny lower bounds: the product of two t's may underflow */
+								r0 = miss[b] ? 0.0 : rcp_full(t[b]);
+								r1 = miss[b + 1] ? 0.0 : rcp_full(t[b + 1]);
+							} else {
+								const double rp = rcp_full(pp);
+								r0 = miss[b] ? 0.0 : rp * t[b + 1];
+								r1 = miss[b + 1] ? 0.0 : rp * t[b];
+							}
+#pragma unroll
+							for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b][k], r0, acc[k]);
+#pragma unroll
+							for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[b + 1][k], r1, acc[k]);
+						}
+						if (SAFE) {
+							/* projection off: a negative t in a cell that carries a copy is NaN in the reference's log and ends the
+							 * run (em_alg.c:106-110); two such factors must not cancel in the product */
+							prod *= t[b] < 0.0 ? __builtin_nan("") : t[b];
+							rescale(prod, ex);
+							prod *= t[b + 1] < 0.0 ? __builtin_nan("") : t[b + 1];
+							rescale(prod, ex);
+						} else {
+							prod *= pp;
+						}
+						if constexpr (DUAL) {	/* the second set's t of the same two copies: gather, dot product, into its own log-product */
+							double t2[2];
+#pragma unroll
+							for (int bb = 0; bb < 2; bb++) {
+								const double2 *pr = reinterpret_cast<const double2 *>(tile2 + (size_t)row[b + bb] * KP);
+								double pc2[KP];
+#pragma unroll
+								for (int k = 0; k < KP / 2; k++) {
+									const double2 v = pr[k];
+									pc2[2 * k] = v.x;
+									pc2[2 * k + 1] = v.y;
+								}
+								t2[bb] = q2[0] * pc2[0];
+#pragma unroll
+								for (int k = 1; k < K; k++) t2[bb] = __builtin_fma(q2[k], pc2[k], t2[bb]);
+								if (!NOMISS) t2[bb] = miss[b + bb] ? 1.0 : t2[bb];
+							}
+							prod2 *= t2[0] * t2[1];
+						}
+					}
+				} else {
+					for (int bb = 0; bb < pl; bb++) {	/* any other ploidy: one copy at a time */
+						const unsigned mraw = g.copy(j, bb, pl);
+						const bool miss = (mraw == MCHIP_MISSING) || !active;
+						const unsigned mm = miss ? 0u : mraw;
+						const double *pr = tile + (size_t)(base + (int)mm) * KP;
+						double pc[K];
+#pragma unroll
+						for (int k = 0; k < K; k++) pc[k] = pr[k];
+						double t = q[0] * pc[0];
+#pragma unroll
+						for (int k = 1; k < K; k++) t = __builtin_fma(q[k], pc[k], t);
+						if (ACCUM) {
+							const double r = miss ? 0.0 : rcp_full(t);
+#pragma unroll
+							for (int k = 0; k < K; k++) acc[k] = __builtin_fma(pc[k], r, acc[k]);
+						}
+						prod *= miss ? 1.0 : (t < 0.0 ? __builtin_nan("") : t);		/* as above: a negative t must end in NaN */
+						rescale(prod, ex);
+					}
+				}
+			};
+			/* !SAFE: the product is looked at every flush_blocks units of 16 multiplications: a block of 8 diploid loci,
+			 * half a block of tetraploid ones (the host sizes flush_blocks for that, mchip_set_model) */
+			auto tick = [&]() __attribute__((always_inline)) {
+				if (!SAFE) {
+					if (++blk >= a.flush_blocks) {
+						blk = 0;
+						rescale(prod, ex);
+						if (DUAL) rescale(prod2, ex2);
+					}
+				}
+			};
+			const int nloc = l1 - lb * 8;
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				if (j < nloc) one_locus(j);
+				if (PL == 4 && j == 3) tick();
+			}
+			tick();
+			if constexpr (GLDS) {
+				glds_wait();	/* this wave's direct copies of the next tile have landed */
+			} else if (staged) {
+#pragma unroll
+				for (int s2 = 0; s2 < WSTAGE; s2++) {
+					const int x = lane + s2 * 64;
+					if (x < nel_next) dst[(x / K) * KP + (x % K)] = stage[s2];
+					if constexpr (DUAL) { if (x < nel_next) dst2[(x / K) * KP + (x % K)] = stage2[s2]; }
+				}
+			}
+			g = gn;
+#pragma unroll
+			for (int x = 0; x <= 8; x++) E[x] = E[x + 8];
+#pragma unroll
+			for (int x = 0; x < 8; x++) E[9 + x] = En[x];
+			/* (no barrier: the tile is this wave's own, and a wave's LDS operations complete in the order it issued them) */
+		}
+	}
+	double ll = (double)ex * 0.693147180559945309417 + log(prod);
+	double ll2 = DUAL ? (double)ex2 * 0.693147180559945309417 + log(prod2) : 0.0;
+	if (W > 1) {
+		/* waves 1 .. W-1 hand their sums and log likelihoods to wave 0, in wave order, through one wave's worth of LDS taken in turns
+		 * (the tiles have served their purpose once every wave has left its loop) */
+		__syncthreads();
+		for (int x = 1; x < W; x++) {
+			if (wv == x) {
+#pragma unroll
+				for (int k = 0; k < K; k++) lds[k * 64 + lane] = acc[k];
+				lds[K * 64 + lane] = ll;
+				if (DUAL) lds[(K + 1) * 64 + lane] = ll2;
+			}
+			__syncthreads();
+			if (wv == 0) {
+#pragma unroll
+				for (int k = 0; k < K; k++) acc[k] += lds[k * 64 + lane];
+				ll += lds[K * 64 + lane];
+				if (DUAL) ll2 += lds[(K + 1) * 64 + lane];
+			}
+			__syncthreads();
+		}
+	}
+	if (wv == 0) {
+		if (ACCUM && active) {
+			double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
+#pragma unroll
+			for (int k = 0; k < K; k++) out[k] = acc[k];
+		}
+		const double tot = wave_total(active ? ll : 0.0);
+		if (lane == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+		if (DUAL) {
+			const double tot2 = wave_total(active ? ll2 : 0.0);
+			if (lane == 0) a.llpart2[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot2;
+		}
+	}
+}
+
 /* ---------------------------------------------------------------- individual pass, every locus biallelic (SNP data)
  * When every locus has exactly two allele columns (diploid data without missing-data phantom slots) column c of locus l is
  * 2l + m and the two rows of a locus are wave-uniform: they come through the scalar cache as SGPR operands of the FMAs, no
@@ -867,12 +1241,16 @@ __global__ __launch_bounds__(QBLOCK, sparse_min_waves(PL, ACCUM)) void k_individ
  * the genotype only selects which of them enter the log-product, and the S-side sums take P_0 n_0/t_0 + P_1 n_1/t_1 with one
  * reciprocal.  The stand-alone log-likelihood pass, LDS-bound in the general kernel, becomes FP64-bound here. */
 template <bool ACCUM, bool NOMISS>
-__global__ __launch_bounds__(QBLOCK) void k_individual_bial(mchip_pass_args a)
+__global__ __launch_bounds__(64 * MCHIP_IND_WAVES_MAX) void k_individual_bial(mchip_pass_args a)
 {
-	if (a.stop && *a.stop) return;		/* batched run already stopped (wave-uniform) */
+	if (a.stop && *a.stop) return;		/* batched run already stopped (uniform over the grid) */
 	if (ACCUM && a.skip_ind && *a.skip_ind) return;
-	__shared__ double red[QBLOCK];
-	const int i_raw = blockIdx.x * QBLOCK + threadIdx.x;
+	/* cooperating waves, as k_individual_sparse_w: a.ind_waves waves over the same 64 individuals, wave w at sub-chunk w */
+	__shared__ double xch[K + 1][64];
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int W = a.ind_waves;
+	const int i_raw = blockIdx.x * 64 + lane;
 	const bool active = i_raw < a.I;
 	const int i = active ? i_raw : a.I - 1;
 	double q[K], acc[K];
@@ -881,9 +1259,11 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_bial(mchip_pass_args a)
 		q[k] = a.Q[(size_t)i * a.qstride + k];
 		acc[k] = 0.0;
 	}
-	const int l0 = blockIdx.y * a.lchunk;
-	const int l1 = min(a.L, l0 + a.lchunk);
-	const int lb0 = l0 >> 3, lb_end = (l1 + 7) >> 3;
+	const int l0raw = (int)(blockIdx.y * W + wv) * a.lchunk;
+	const bool any = l0raw < a.L;		/* (wave-uniform; a trailing wave of the last workgroup may have nothing: empty loop) */
+	const int l0 = any ? l0raw : 0;
+	const int l1 = any ? min(a.L, l0 + a.lchunk) : 0;
+	const int lb0 = l0 >> 3, lb_end = any ? (l1 + 7) >> 3 : lb0;
 	double prod = 1.0;
 	int blk = 0, ex = 0;
 	geno_group<2> g, gn;
@@ -929,14 +1309,30 @@ __global__ __launch_bounds__(QBLOCK) void k_individual_bial(mchip_pass_args a)
 		}
 		g = gn;
 	}
-	const double ll = (double)ex * 0.693147180559945309417 + log(prod);
-	if (ACCUM && active) {
-		double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
+	double ll = (double)ex * 0.693147180559945309417 + log(prod);
+	for (int x = 1; x < W; x++) {	/* waves 1 .. W-1 hand their sums to wave 0, in wave order */
+		if (wv == x) {
 #pragma unroll
-		for (int k = 0; k < K; k++) out[k] = acc[k];
+			for (int k = 0; k < K; k++) xch[k][lane] = acc[k];
+			xch[K][lane] = ll;
+		}
+		__syncthreads();
+		if (wv == 0) {
+#pragma unroll
+			for (int k = 0; k < K; k++) acc[k] += xch[k][lane];
+			ll += xch[K][lane];
+		}
+		__syncthreads();
 	}
-	const double tot = block_sum<QBLOCK>(active ? ll : 0.0, red);
-	if (threadIdx.x == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+	if (wv == 0) {
+		if (ACCUM && active) {
+			double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
+#pragma unroll
+			for (int k = 0; k < K; k++) out[k] = acc[k];
+		}
+		const double tot = wave_total(active ? ll : 0.0);
+		if (lane == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+	}
 }
 
 /* ---------------------------------------------------------------- mixture model (em_alg.c:763-1011)
@@ -1275,8 +1671,17 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_project_q(int nrows, double *Q,
 
 /* ---------------------------------------------------------------- launchers */
 inline dim3 column_grid(const mchip_pass_args &a) { return dim3((a.T + MCHIP_BLOCK - 1) / MCHIP_BLOCK, a.n_ichunks); }
+/* packed-count column pass (cooperating waves): 64 columns per workgroup, one slab per workgroup row */
+inline dim3 counts_grid(const mchip_pass_args &a) { return dim3((a.T + 63) / 64, mchip_col_slabs(a)); }
 inline dim3 indiv_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK - 1) / QBLOCK, a.n_lchunks); }
 inline dim3 sparse_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK / SPLIT - 1) / (QBLOCK / SPLIT), a.n_lchunks); }
+/* the cooperating forms (K <= 27): 64 individuals per workgroup, a.ind_waves waves, one slab per workgroup row */
+inline dim3 coop_grid(const mchip_pass_args &a) { return dim3((a.I + 63) / 64, mchip_ind_slabs(a)); }
+inline size_t coop_lds_bytes(const mchip_pass_args &a, int sets)
+{
+	const size_t tiles = (size_t)a.ind_waves * 2 * sets * tile_stride(a.tile_cols), hand_over = (size_t)(K + 2) * 64;
+	return (tiles > hand_over ? tiles : hand_over) * sizeof(double);
+}
 
 /* a.sparse: the column pass only accumulates the N-side sums; S-side sums and logL come from the sparse
  * individual pass.  Otherwise (loci with more alleles than the LDS tile is sized for) the dense pair is used:
@@ -1284,7 +1689,7 @@ inline dim3 sparse_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK / 
 void launch_accum_p(const mchip_pass_args &a, hipStream_t s)
 {
 	if constexpr (CSPLIT > 1) {
-		if (a.sparse && a.count_bits && !getenv("MCHIP_NO_COL_SPLIT")) {
+		if (a.sparse && a.count_bits && !a.no_col_split) {
 			const dim3 grid((a.T + MCHIP_BLOCK / CSPLIT - 1) / (MCHIP_BLOCK / CSPLIT), a.n_ichunks);
 			if (a.count_bits == 2 && a.safe_rcp) hipLaunchKernelGGL((k_column_counts_split<2, true>), grid, dim3(MCHIP_BLOCK), 0, s, a);
 			else if (a.count_bits == 2) hipLaunchKernelGGL((k_column_counts_split<2, false>), grid, dim3(MCHIP_BLOCK), 0, s, a);
@@ -1293,10 +1698,10 @@ void launch_accum_p(const mchip_pass_args &a, hipStream_t s)
 			return;
 		}
 	}
-	if (a.sparse && a.count_bits == 2 && a.safe_rcp) { hipLaunchKernelGGL((k_column_counts<2, false, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
-	if (a.sparse && a.count_bits == 4 && a.safe_rcp) { hipLaunchKernelGGL((k_column_counts<4, false, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
-	if (a.sparse && a.count_bits == 2) { hipLaunchKernelGGL((k_column_counts<2, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
-	if (a.sparse && a.count_bits == 4) { hipLaunchKernelGGL((k_column_counts<4, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
+	if (a.sparse && a.count_bits == 2 && a.safe_rcp) { hipLaunchKernelGGL((k_column_counts<2, false, true>), counts_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
+	if (a.sparse && a.count_bits == 4 && a.safe_rcp) { hipLaunchKernelGGL((k_column_counts<4, false, true>), counts_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
+	if (a.sparse && a.count_bits == 2) { hipLaunchKernelGGL((k_column_counts<2, false>), counts_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
+	if (a.sparse && a.count_bits == 4) { hipLaunchKernelGGL((k_column_counts<4, false>), counts_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
 	if (a.sparse) {
 		if (a.ploidy == 2) hipLaunchKernelGGL((k_column_pass<2, true, false, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
 		else hipLaunchKernelGGL((k_column_pass<0, true, false, false>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
@@ -1320,38 +1725,65 @@ template <bool ACCUM> void launch_sparse(const mchip_pass_args &a, hipStream_t s
 	 * LDS-bound in the general kernel), the S-side pass only from K = 10 (it is FP64-bound, and the dense-over-two-alleles
 	 * form costs more instructions per locus: +8-19 % below that) */
 	constexpr bool bial_pays = SPLIT == 1 && (ACCUM ? (K >= 10) : (K >= 6));	/* (its grid and partials are one lane per individual) */
-	if (bial_pays && a.biallelic && a.ploidy == 2 && !safe) {
-		if (nomiss) hipLaunchKernelGGL((k_individual_bial<ACCUM, true>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
-		else hipLaunchKernelGGL((k_individual_bial<ACCUM, false>), indiv_grid(a), dim3(QBLOCK), 0, s, a);
-		return;
-	}
+	if constexpr (SPLIT == 1) {
+		const dim3 grid = coop_grid(a), block(64 * a.ind_waves);
+		const size_t cl = coop_lds_bytes(a, 1);
+		if (bial_pays && a.biallelic && a.ploidy == 2 && !safe) {
+			if (nomiss) hipLaunchKernelGGL((k_individual_bial<ACCUM, true>), grid, block, 0, s, a);
+			else hipLaunchKernelGGL((k_individual_bial<ACCUM, false>), grid, block, 0, s, a);
+			return;
+		}
+#define MCHIP_SPARSE_W(PLV) \
+		do { \
+			if (nomiss && !safe) hipLaunchKernelGGL((k_individual_sparse_w<PLV, ACCUM, false, true>), grid, block, cl, s, a); \
+			else if (!safe) hipLaunchKernelGGL((k_individual_sparse_w<PLV, ACCUM, false, false>), grid, block, cl, s, a); \
+			else hipLaunchKernelGGL((k_individual_sparse_w<PLV, ACCUM, true, false>), grid, block, cl, s, a); \
+		} while (0)
+		if (a.ploidy == 2) MCHIP_SPARSE_W(2);
+		else if (a.ploidy == 4) MCHIP_SPARSE_W(4);
+		else hipLaunchKernelGGL((k_individual_sparse_w<0, ACCUM, true, false>), grid, block, cl, s, a);
+#undef MCHIP_SPARSE_W
+	} else {
 #define MCHIP_SPARSE(PLV) \
-	do { \
-		if (nomiss && !safe) hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, false, true>), sparse_grid(a), dim3(QBLOCK), lds, s, a); \
-		else if (!safe) hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, false, false>), sparse_grid(a), dim3(QBLOCK), lds, s, a); \
-		else hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, true, false>), sparse_grid(a), dim3(QBLOCK), lds, s, a); \
-	} while (0)
-	if (a.ploidy == 2) MCHIP_SPARSE(2);
-	else if (a.ploidy == 4) MCHIP_SPARSE(4);
-	else hipLaunchKernelGGL((k_individual_sparse<0, ACCUM, true, false>), sparse_grid(a), dim3(QBLOCK), lds, s, a);
+		do { \
+			if (nomiss && !safe) hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, false, true>), sparse_grid(a), dim3(QBLOCK), lds, s, a); \
+			else if (!safe) hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, false, false>), sparse_grid(a), dim3(QBLOCK), lds, s, a); \
+			else hipLaunchKernelGGL((k_individual_sparse<PLV, ACCUM, true, false>), sparse_grid(a), dim3(QBLOCK), lds, s, a); \
+		} while (0)
+		if (a.ploidy == 2) MCHIP_SPARSE(2);
+		else if (a.ploidy == 4) MCHIP_SPARSE(4);
+		else hipLaunchKernelGGL((k_individual_sparse<0, ACCUM, true, false>), sparse_grid(a), dim3(QBLOCK), lds, s, a);
 #undef MCHIP_SPARSE
+	}
 }
 /* the dual pass exists where both of its halves would run the sparse kernel with shared reciprocals (so that its results are
  * theirs bit for bit) and the second set's registers still fit */
-inline size_t dual_lds_bytes(const mchip_pass_args &a) { return (4 * (size_t)a.tile_cols * KP + QBLOCK) * sizeof(double); }
 int dual_available(const mchip_pass_args &a)
 {
 	if (K > 12 || !a.sparse || a.flush_blocks < 1 || a.ploidy != 2) return 0;
 	if (a.biallelic && K >= 6) return 0;	/* launch_sparse takes k_individual_bial for one or both passes */
-	return dual_lds_bytes(a) <= 64 * 1024;
+	return coop_lds_bytes(a, 2) <= 64 * 1024;
 }
 void launch_accum_q_dual(const mchip_pass_args &a, hipStream_t s)
 {
 	if constexpr (K <= 12) {
-		const size_t lds = dual_lds_bytes(a);
-		if (!a.has_missing) hipLaunchKernelGGL((k_individual_sparse<2, true, false, true, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
-		else hipLaunchKernelGGL((k_individual_sparse<2, true, false, false, true>), indiv_grid(a), dim3(QBLOCK), lds, s, a);
+		const size_t lds = coop_lds_bytes(a, 2);
+		if (!a.has_missing) hipLaunchKernelGGL((k_individual_sparse_w<2, true, false, true, true>), coop_grid(a), dim3(64 * a.ind_waves), lds, s, a);
+		else hipLaunchKernelGGL((k_individual_sparse_w<2, true, false, false, true>), coop_grid(a), dim3(64 * a.ind_waves), lds, s, a);
 	}
+}
+/* what the launchers leave behind (mchip_ktable) */
+int col_slabs(const mchip_pass_args &a, int mix)
+{
+	if (mix) return a.count_bits ? mchip_col_slabs(a) : a.n_ichunks;
+	return (a.sparse && a.count_bits && (CSPLIT == 1 || a.no_col_split)) ? mchip_col_slabs(a) : a.n_ichunks;
+}
+int ind_slabs(const mchip_pass_args &a) { return (a.sparse && SPLIT == 1) ? mchip_ind_slabs(a) : a.n_lchunks; }
+int ind_ll_parts(const mchip_pass_args &a)
+{
+	if (a.sparse && SPLIT == 1) return ((a.I + 63) / 64) * mchip_ind_slabs(a);
+	if (a.sparse) return ((a.I + QBLOCK / SPLIT - 1) / (QBLOCK / SPLIT)) * a.n_lchunks;
+	return ((a.T + MCHIP_BLOCK - 1) / MCHIP_BLOCK) * a.n_ichunks;	/* dense pair: the column pass takes the log likelihood */
 }
 void launch_loglik(const mchip_pass_args &a, hipStream_t s)
 {
@@ -1383,8 +1815,8 @@ void launch_mix_finalize(int I, int n_lchunks, const double *Vpart, const double
 }
 void launch_mix_column(const mchip_pass_args &a, hipStream_t s)
 {
-	if (a.count_bits == 2) { hipLaunchKernelGGL((k_column_counts<2, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
-	if (a.count_bits == 4) { hipLaunchKernelGGL((k_column_counts<4, true>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
+	if (a.count_bits == 2) { hipLaunchKernelGGL((k_column_counts<2, true>), counts_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
+	if (a.count_bits == 4) { hipLaunchKernelGGL((k_column_counts<4, true>), counts_grid(a), dim3(MCHIP_BLOCK), 0, s, a); return; }
 	if (a.ploidy == 2) hipLaunchKernelGGL((k_mix_column<2>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
 	else hipLaunchKernelGGL((k_mix_column<0>), column_grid(a), dim3(MCHIP_BLOCK), 0, s, a);
 }
@@ -1422,6 +1854,7 @@ const mchip_ktable *MCHIP_CAT(mchip_ktable_get_, MCHIP_K)()
 	static mchip_ktable t = {
 		launch_accum_p, launch_loglik, launch_accum_q, launch_part_p, launch_part_q, launch_finalize_q, launch_project_q,
 		launch_mix_gather, launch_mix_finalize, launch_mix_column, dual_available, launch_accum_q_dual,
+		col_slabs, ind_slabs, ind_ll_parts,
 	};
 	return &t;
 }

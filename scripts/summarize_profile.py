@@ -26,7 +26,41 @@ def ours(name):
     return "at::" not in name and "rocclr" not in name and ("k_" in name)
 
 
+def build_id():
+    """sha256 of the HIP library in the tree (what the profiled command loaded) and, where the tree is a git checkout (the build
+    container: the GPU box gets a snapshot without .git), the commit"""
+    import hashlib
+    import subprocess
+    lib = os.path.join(ROOT, "multiclust_amd", "lib", "libmulticlust_hip.so")
+    out = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None, "commit": None}
+    try:
+        res = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        if res.returncode == 0:
+            out["commit"] = res.stdout.strip()
+            dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "multiclust_amd", "include", "Makefile"],
+                                   stdout=subprocess.PIPE, text=True).stdout.strip()
+            out["tree_dirty"] = bool(dirty)
+    except OSError:
+        pass
+    return out
+
+
+def stamp_commit(path):
+    """`summarize_profile.py --stamp profiles/<file>_traffic.json`: run in the build container on a summary that came back from the
+    GPU box, adds the commit to its _build record when the library in this tree is the one that was profiled"""
+    d = json.load(open(path))
+    here = build_id()
+    if d.get("_build", {}).get("library_sha256") != here["library_sha256"]:
+        raise SystemExit("%s describes another build of the library than the one in this tree" % path)
+    d["_build"].update(commit=here["commit"], tree_dirty=here.get("tree_dirty"))
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+    print("stamped", path, here["commit"])
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--stamp":
+        stamp_commit(sys.argv[2])
+        return
     tag, stats_dir = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     f = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
@@ -75,6 +109,8 @@ def main():
                 "WRITE_SIZE_KiB_per_launch": write,
                 "hbm_bytes_per_launch_corrected": (2 * fetch * 1024 if fetch is not None else 0) + (write * 1024 if write is not None else 0),
             }
+        # which build these counters describe: bench.py compares the digest with the library it has loaded (`traffic_build_matches`)
+        res["_build"] = build_id()
         out = os.path.join(ROOT, "profiles", tag + "_traffic.json")
         json.dump(res, open(out, "w"), indent=1, sort_keys=True)
         print("wrote", out)
