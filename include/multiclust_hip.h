@@ -109,7 +109,15 @@ int mchip_set_init_genotypes(mchip_context *ctx, const uint8_t *geno);
 int mchip_set_model(mchip_context *ctx, int K, int admixture, int eta_constrained, int do_projection,
 		    double eta_lower_bound, double p_lower_bound, int n_secants);
 
-/* Parameter slots: mod->vpklm[slot], mod->vetaik[slot] / mod->vetak[slot]. */
+/* Parameter slots: mod->vpklm[slot], mod->vetaik[slot] / mod->vetak[slot].
+ * Rows of individuals without a single observed copy (mchip_empty_individuals): the reference holds 0 / 0 = NaN for them from the
+ * first M step on (em_alg.c:685-690); the device holds a finite 1 / K (nothing such a row is multiplied into carries a count) and
+ * remembers PER SLOT whether the slot's rows stand for that NaN: set by whatever writes the slot from an M step (mchip_em_step's
+ * `to`, mchip_em_run, every slot of mchip_accel_run, mchip_mstep_from_*partition), inherited by mchip_copy_slot,
+ * mchip_accel_update and mchip_multisecant_update from the slot they start from, cleared by mchip_init_from_allele_centers
+ * (counts start at 1 there: the row is 1 / K in the reference too).  mchip_get_q reports such rows as NaN; mchip_set_q accepts
+ * them back -- a NaN row of such an individual is stored as 1 / K and the slot keeps reporting NaN (a get_q / set_q round trip
+ * is safe), a finite row is stored and reported as given. */
 int mchip_set_p(mchip_context *ctx, int slot, const double *p);
 int mchip_get_p(mchip_context *ctx, int slot, double *p);
 int mchip_set_q(mchip_context *ctx, int slot, const double *q);

@@ -78,7 +78,8 @@ struct mchip_context {
 	int count_bits, has_missing;
 	int first_empty;	/* first individual without a single observed copy, or -1 */
 	std::vector<int> empty_rows;	/* all of them: their mixing proportions are 0 / 0 in the reference (em_alg.c:685-690) */
-	int empty_rows_nan;	/* an M step has run since the parameters were set: mchip_get_q reports those rows as the reference has them */
+	int empty_rows_nan[3];	/* per slot: the slot's rows of such individuals stand for the reference's 0 / 0 (an M step wrote the slot, or
+				 * something computed from such a slot did, or NaN rows were uploaded): mchip_get_q reports them as NaN */
 	unsigned long long nnz_cells, n_copies;	/* cells with n_ic > 0, non-missing allele copies (mchip_data_counts) */
 	int counts_valid;
 	size_t geno_bytes_A, geno_bytes_S;
@@ -109,6 +110,7 @@ struct mchip_context {
 	/* workspaces */
 	int ichunk, n_ichunks, lchunk, n_lchunks, n_llpart, flush_blocks, safe_rcp, sparse;
 	int ind_waves;			/* waves per workgroup of the cooperating individual-side kernels (mchip_internal.h) */
+	int xcd_rows;			/* their slab rows come in whole groups of eight: one row, one XCD */
 	/* testing / tuning knobs of the environment (README), read when a context is created and again with every data set and every
 	 * model -- never on a launch path */
 	struct {
@@ -116,7 +118,6 @@ struct mchip_context {
 		int per_cu_col, per_cu_ind, geometry_given;
 		double slab_frac;
 	} knob;
-	double *d_ssum;			/* [I][K] chunk-summed S-side sums */
 	double *d_Apart, *d_Spart, *d_llpart, *d_scalars;	/* d_scalars: [0]=logL, [1..3]=dots, [4..]=eta sums */
 	double *d_llpart2;		/* partial log likelihoods of the second parameter set of a dual individual pass */
 	double *d_redpart;		/* block partials of the dot products / column sums */
@@ -1064,6 +1065,88 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_p(int L, int K, int T,
 	if (do_projection) michelot_strided(Pto + (size_t)c0 * K + k, K, M, lb, flags ? flags + (size_t)c0 * K + k : nullptr);
 }
 
+/* The same with the memory side done by whole blocks.  k_finalize_p's (l, k) threads walk their M elements K doubles apart: every
+ * load instruction of a wave touches eight half-used cache lines, and the slab reads ran at 2.9 TB/s (40 us per launch at config
+ * 3, the largest of the small kernels of a cycle).  Here a block owns FP_LOCI consecutive loci, i.e. one contiguous run of
+ * (c1 - c0) * K elements of every slab: phase 1 adds the slabs element by element, coalesced, into LDS (same sums, same order:
+ * ordered_sum over the slabs, times P[from], plus the additive bound); phase 2 is k_finalize_p's arithmetic per (l, k) on the LDS
+ * copy; phase 3 stores the run, coalesced.  Same bits as k_finalize_p.  Used while FP_LOCI loci of max_M alleles fit the tile. */
+constexpr int FP_TILE = 1024;	/* doubles of LDS per block: four elements per thread, all of a thread's slab loads in flight at once */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_p_tile(int L, int K, int T, const int32_t *__restrict__ toff, int loci_per_block,
+		int n_slabs, const double *__restrict__ Apart, const double *Pfrom, double *Pto,
+		int weighted, double add_lb, int do_projection, double lb, const int *stop = nullptr)
+{
+	__shared__ double tile[FP_TILE];
+	if (stop && *stop) return;
+	const int l0 = blockIdx.x * loci_per_block, l1 = min(L, l0 + loci_per_block);
+	const int c0 = toff[l0], c1 = toff[l1];
+	const int nel = (c1 - c0) * K;
+	const size_t e0 = (size_t)c0 * K, slab = (size_t)T * K;
+	if (nel > 0) {	/* a thread's (up to) four elements side by side: their loads of one slab go out together, the sums keep the slab order */
+		double v[FP_TILE / MCHIP_BLOCK];
+#pragma unroll
+		for (int y = 0; y < FP_TILE / MCHIP_BLOCK; y++) v[y] = 0.0;
+		for (int sl = 0; sl < n_slabs; sl++) {
+			double w[FP_TILE / MCHIP_BLOCK];
+#pragma unroll
+			for (int y = 0; y < FP_TILE / MCHIP_BLOCK; y++) {
+				const int x = min((int)threadIdx.x + y * MCHIP_BLOCK, nel - 1);
+				w[y] = Apart[(size_t)sl * slab + e0 + x];
+			}
+#pragma unroll
+			for (int y = 0; y < FP_TILE / MCHIP_BLOCK; y++) v[y] += w[y];
+		}
+#pragma unroll
+		for (int y = 0; y < FP_TILE / MCHIP_BLOCK; y++) {
+			const int x = threadIdx.x + y * MCHIP_BLOCK;
+			if (x < nel) {
+				double t = v[y];
+				if (weighted) t *= Pfrom[e0 + x];
+				tile[x] = t + add_lb;
+			}
+		}
+	}
+	__syncthreads();
+	for (int y = threadIdx.x; y < (l1 - l0) * K; y += MCHIP_BLOCK) {
+		const int k = y % K, l = l0 + y / K;
+		const int m0 = toff[l] - c0, M = toff[l + 1] - toff[l];
+		double *col = tile + (size_t)m0 * K + k;	/* the locus's M values of cluster k, K doubles apart */
+		double temp = 0.0;
+		if (M <= 8) {
+			double v[8];
+#pragma unroll
+			for (int m = 0; m < 8; m++) {
+				v[m] = 0.0;
+				if (m < M) {
+					v[m] = col[(size_t)m * K];
+					temp += v[m];
+				}
+			}
+#pragma unroll
+			for (int m = 0; m < 8; m++)
+				if (m < M) v[m] /= temp;
+			if (do_projection) michelot_small(v, M, lb);
+#pragma unroll
+			for (int m = 0; m < 8; m++)
+				if (m < M) col[(size_t)m * K] = v[m];
+		} else {
+			for (int m = 0; m < M; m++) temp += col[(size_t)m * K];
+			for (int m = 0; m < M; m++) col[(size_t)m * K] /= temp;
+			if (do_projection) michelot_strided(col, K, M, lb, nullptr);	/* (M <= 64 here: the fixed set is a bit mask) */
+		}
+	}
+	__syncthreads();
+	for (int x = threadIdx.x; x < nel; x += MCHIP_BLOCK) Pto[e0 + x] = tile[x];
+}
+
+/* loci per block of k_finalize_p_tile for this data set and K, or 0 where a locus can outgrow the tile (k_finalize_p then) */
+static int finalize_p_loci(int K, int max_M)
+{
+	if (max_M > 64 || max_M < 1) return 0;
+	const int n = FP_TILE / (max_M * K);
+	return n >= 4 ? n : 0;
+}
+
 /* projection of every (l,k) block of a P slot (accelerated updates, accel_em.c:474-475) */
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_project_p(int L, int K, const int32_t *__restrict__ toff, double *P,
 		double lb, uint8_t *flags, const int *stop = nullptr)
@@ -1387,7 +1470,7 @@ static void free_model(mchip_context *ctx)
 	drop_graphs(ctx);
 	for (int s = 0; s < 3; s++) { dfree(ctx->d_p[s]); dfree(ctx->d_q[s]); }
 	for (int s = 0; s < MCHIP_MAX_SECANTS; s++) { dfree(ctx->d_up[s]); dfree(ctx->d_vp[s]); dfree(ctx->d_uq[s]); dfree(ctx->d_vq[s]); }
-	dfree(ctx->d_sik); dfree(ctx->d_stage); dfree(ctx->d_logp); dfree(ctx->d_ssum); dfree(ctx->d_Apart); dfree(ctx->d_Spart); dfree(ctx->d_llpart); dfree(ctx->d_llpart2);
+	dfree(ctx->d_sik); dfree(ctx->d_stage); dfree(ctx->d_logp); dfree(ctx->d_Apart); dfree(ctx->d_Spart); dfree(ctx->d_llpart); dfree(ctx->d_llpart2);
 	dfree(ctx->d_redpart); dfree(ctx->d_flags);
 	ctx->K = 0;
 	ctx->parked_K = 0;
@@ -1429,8 +1512,24 @@ static mchip_pass_args pass_args(mchip_context *ctx, int slot)
 	a.sparse = ctx->sparse; a.tile_cols = 8 * ctx->max_M;
 	a.biallelic = (ctx->min_M == 2 && ctx->max_M == 2 && !ctx->knob.no_bial) ? 1 : 0;
 	a.ind_waves = ctx->ind_waves;
+	a.xcd_rows = ctx->xcd_rows;
 	a.no_col_split = ctx->knob.no_col_split;
 	return a;
+}
+
+/* P[to] from n_slabs slabs of N-side sums: the tiled form where the data set allows it */
+static void launch_finalize_p(mchip_context *ctx, int n_slabs, const double *slabs, int from, int to, int weighted, double add_lb,
+			      int do_projection, const int *stop)
+{
+	const int per = finalize_p_loci(ctx->K, ctx->max_M);
+	if (per)
+		hipLaunchKernelGGL(k_finalize_p_tile, dim3((ctx->L + per - 1) / per), dim3(MCHIP_BLOCK), 0, ctx->stream,
+				   ctx->L, ctx->K, ctx->T, ctx->d_toff, per, n_slabs, slabs, ctx->d_p[from], ctx->d_p[to],
+				   weighted, add_lb, do_projection, ctx->p_lb, stop);
+	else
+		hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
+				   ctx->L, ctx->K, ctx->T, ctx->d_toff, n_slabs, slabs, ctx->d_p[from], ctx->d_p[to],
+				   weighted, add_lb, do_projection, ctx->p_lb, ctx->d_flags, stop);
 }
 
 /* the "bad input" word of the layout kernels: the last double of d_scalars (slots 0..47 are in use), so that an
@@ -1665,7 +1764,7 @@ int mchip_set_genotypes(mchip_context *ctx, int I, int L, int ploidy, const int3
 	/* an individual whose every copy is missing (one pass that stops at each individual's first observed copy: O(I) on real data) */
 	ctx->first_empty = -1;
 	ctx->empty_rows.clear();
-	ctx->empty_rows_nan = 0;
+	for (int sl = 0; sl < 3; sl++) ctx->empty_rows_nan[sl] = 0;
 	for (int i = 0; i < I; i++) {
 		const uint8_t *row = geno + (size_t)i * L * ploidy;
 		size_t x = 0;
@@ -1699,7 +1798,7 @@ int mchip_copy_genotypes(mchip_context *ctx, const mchip_context *src)
 	ctx->has_missing = src->has_missing;
 	ctx->first_empty = src->first_empty;
 	ctx->empty_rows = src->empty_rows;
-	ctx->empty_rows_nan = 0;
+	for (int sl = 0; sl < 3; sl++) ctx->empty_rows_nan[sl] = 0;
 	ctx->count_bits = src->count_bits;
 	ctx->counts_valid = src->counts_valid;
 	ctx->nnz_cells = src->nnz_cells;
@@ -1854,7 +1953,6 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	HIPCHK(hipMalloc((void **)&ctx->d_sik, (size_t)ctx->I * K * sizeof(double)));
 	HIPCHK(hipMemsetAsync(ctx->d_sik, 0, (size_t)ctx->I * K * sizeof(double), ctx->stream));
 	HIPCHK(hipMalloc((void **)&ctx->d_stage, KT * sizeof(double)));
-	HIPCHK(hipMalloc((void **)&ctx->d_ssum, (size_t)ctx->I * K * sizeof(double)));
 	if (!admixture) HIPCHK(hipMalloc((void **)&ctx->d_logp, KT * sizeof(double)));
 
 	/* launch geometry.  Both passes are FP64-issue-bound and every workgroup does the same amount of work, so
@@ -1912,12 +2010,18 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	/* cooperating waves (mchip_internal.h): chunks are still what ONE WAVE takes; a workgroup of the sparse individual-side kernels
 	 * is ind_waves of them, so a whole number of workgroups wants a multiple of that many chunks where the caps allow it */
 	ctx->ind_waves = (admixture && ctx->sparse && mchip_ind_split(K) == 1) ? mchip_ind_waves(K, 8 * ctx->max_M) : 1;
-	if (ctx->ind_waves > 1) {
-		const int up = ((want + ctx->ind_waves - 1) / ctx->ind_waves) * ctx->ind_waves;
-		if (up <= cap && up <= lblocks) want = up;
+	const bool ind_coop = admixture && ctx->sparse && mchip_ind_split(K) == 1;
+	if (ind_coop) {
+		/* ... and a multiple of eight slab rows where possible: the sparse kernel then keeps a row on one XCD (coop_rows() in
+		 * mchip_kernels_k.hip), and eight XCDs with 52 rows between them would have 7 and 6 each */
+		const int w8 = 8 * ctx->ind_waves, w1 = ctx->ind_waves;
+		const int up8 = ((want + w8 - 1) / w8) * w8, up1 = ((want + w1 - 1) / w1) * w1;
+		if (up8 <= cap && up8 <= lblocks) want = up8;
+		else if (up1 <= cap && up1 <= lblocks) want = up1;
 	}
 	ctx->lchunk = ((lblocks + want - 1) / want) * 8;
 	ctx->n_lchunks = (ctx->L + ctx->lchunk - 1) / ctx->lchunk;
+	ctx->xcd_rows = (ind_coop && ((ctx->n_lchunks + ctx->ind_waves - 1) / ctx->ind_waves) % 8 == 0) ? 1 : 0;
 	{	/* partial log likelihoods any pass can leave: one per workgroup; no individual-side kernel has fewer than 64 individuals
 		 * per workgroup, no column-side one fewer than 64 columns */
 		const int by_col = ((ctx->T + 63) / 64) * ctx->n_ichunks, by_ind = ((ctx->I + 63) / 64) * ctx->n_lchunks;
@@ -2014,9 +2118,28 @@ int mchip_set_q(mchip_context *ctx, int slot, const double *q)
 	ctx->s_cache_slot = -1;
 	if (!q) return fail(ctx, MCHIP_ERR_INVALID, "null pointer%s", nullptr);
 	HIPCHK(hipSetDevice(ctx->device));
-	HIPCHK(hipMemcpyAsync(ctx->d_q[slot], q, (size_t)ctx->nq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-	HIPCHK(hipStreamSynchronize(ctx->stream));
-	ctx->empty_rows_nan = 0;
+	/* A row of an individual without a single observed copy that comes in as NaN (what mchip_get_q reports for it after an M
+	 * step: a warm start, a checkpoint) is kept on the device as the finite 1 / K k_finalize_q keeps -- a NaN there would reach
+	 * every column's N-side sum through 0 * (1 / NaN) -- and the slot goes on reporting it as NaN; a finite row is taken as it is */
+	int nan_rows = 0;
+	if (ctx->qstride)
+		for (int i : ctx->empty_rows)
+			for (int k = 0; k < ctx->K; k++) nan_rows |= (q[(size_t)i * ctx->K + k] != q[(size_t)i * ctx->K + k]);
+	if (nan_rows) {
+		std::vector<double> clean(q, q + ctx->nq);
+		for (int i : ctx->empty_rows) {
+			bool bad = false;
+			for (int k = 0; k < ctx->K; k++) bad |= (clean[(size_t)i * ctx->K + k] != clean[(size_t)i * ctx->K + k]);
+			if (bad)
+				for (int k = 0; k < ctx->K; k++) clean[(size_t)i * ctx->K + k] = 1.0 / ctx->K;
+		}
+		HIPCHK(hipMemcpyAsync(ctx->d_q[slot], clean.data(), (size_t)ctx->nq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+		HIPCHK(hipStreamSynchronize(ctx->stream));	/* `clean` goes out of scope */
+	} else {
+		HIPCHK(hipMemcpyAsync(ctx->d_q[slot], q, (size_t)ctx->nq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+		HIPCHK(hipStreamSynchronize(ctx->stream));
+	}
+	ctx->empty_rows_nan[slot] = nan_rows;
 	return MCHIP_OK;
 }
 
@@ -2032,7 +2155,7 @@ int mchip_get_q(mchip_context *ctx, int slot, double *q)
 	/* An individual without a single observed copy: the reference's M step gives it 0 / 0 (em_alg.c:685-690; printed "-nan") and the
 	 * row then sits in its arrays untouched by anything else, every zero-count cell being skipped.  The device keeps a finite row
 	 * for it (k_finalize_q: 1 / K) so that nothing it is multiplied into turns NaN, and it is reported here as the reference has it */
-	if (ctx->qstride && ctx->empty_rows_nan)
+	if (ctx->qstride && ctx->empty_rows_nan[slot])
 		for (int i : ctx->empty_rows)
 			for (int k = 0; k < ctx->K; k++) q[(size_t)i * ctx->K + k] = -__builtin_nan("");
 	return MCHIP_OK;
@@ -2092,9 +2215,7 @@ static int run_mixture(mchip_context *ctx, int from, int to, int do_mstep, int m
 		prof_mark(ctx, MCHIP_KERN_ACCUM_P, true);
 		ctx->kt->mix_column(b, ctx->stream);
 		prof_mark(ctx, MCHIP_KERN_ACCUM_P, false);
-		hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
-				   ctx->L, ctx->K, ctx->T, ctx->d_toff, ctx->kt->col_slabs(b, 1), ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
-				   0, ctx->p_lb, ctx->do_projection, ctx->p_lb, ctx->d_flags, stop);
+		launch_finalize_p(ctx, ctx->kt->col_slabs(b, 1), ctx->d_Apart, from, to, 0, ctx->p_lb, ctx->do_projection, stop);
 	}
 	HIPCHK(hipGetLastError());
 	if (mode == 0) ctx->have_ll = 1;
@@ -2129,17 +2250,11 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 	ctx->s_cache_slot = -1;		/* Spart is consumed below; slot `to` is about to change */
 	const int indiv = ctx->qstride != 0;
 	const int s_slabs = ctx->kt->ind_slabs(a), n_slabs = ctx->kt->col_slabs(a, 0);	/* what the passes above left (cooperating waves: a quarter) */
-	if (s_slabs <= 16) {
-		/* few slabs (small data sets, where a launch costs as much as the work): k_finalize_q adds them itself, in slab order */
-		ctx->kt->finalize_q(ctx->I, ctx->K, s_slabs, ctx->d_Spart, ctx->d_q[from], ctx->qstride,
-				    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream, 0.0);
-	} else {
-		const size_t n = (size_t)ctx->I * ctx->K;
-		hipLaunchKernelGGL(k_sum_slabs, dim3(nblk(n, 32)), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_Spart, s_slabs, n, ctx->d_ssum, stop);
-		ctx->kt->finalize_q(ctx->I, ctx->K, 1, ctx->d_ssum, ctx->d_q[from], ctx->qstride,
-				    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream, 0.0);
-	}
-	if (do_mstep && indiv) ctx->empty_rows_nan = 1;
+	/* k_finalize_q adds the slabs itself, four threads per individual (no slab-sum launch in front of it: at config 2 that launch
+	 * was 4 of the 137 us of a step, at config 3 two of the cycle's small kernels) */
+	ctx->kt->finalize_q(ctx->I, ctx->K, s_slabs, ctx->d_Spart, ctx->d_q[from], ctx->qstride,
+			    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream, 0.0);
+	if (do_mstep && indiv) ctx->empty_rows_nan[to] = 1;
 	if (do_mstep) {
 		if (!indiv) {
 			int rc = finalize_shared_eta(ctx, to, stop);
@@ -2150,13 +2265,9 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 			 * (l, k) threads of k_finalize_p reach 2.7 TB/s on the same bytes), k_finalize_p then reads one slab */
 			const size_t n = (size_t)ctx->K * ctx->T;
 			hipLaunchKernelGGL(k_sum_slabs, dim3(nblk(n, 32)), dim3(MCHIP_BLOCK), 0, ctx->stream, ctx->d_Apart, n_slabs, n, ctx->d_stage, stop);
-			hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
-					   ctx->L, ctx->K, ctx->T, ctx->d_toff, 1, ctx->d_stage, ctx->d_p[from], ctx->d_p[to],
-					   1, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags, stop);
+			launch_finalize_p(ctx, 1, ctx->d_stage, from, to, 1, 0.0, ctx->do_projection, stop);
 		} else {
-			hipLaunchKernelGGL(k_finalize_p, dim3(nblk((size_t)ctx->L * ctx->K)), dim3(MCHIP_BLOCK), 0, ctx->stream,
-					   ctx->L, ctx->K, ctx->T, ctx->d_toff, n_slabs, ctx->d_Apart, ctx->d_p[from], ctx->d_p[to],
-					   1, 0.0, ctx->do_projection, ctx->p_lb, ctx->d_flags, stop);
+			launch_finalize_p(ctx, n_slabs, ctx->d_Apart, from, to, 1, 0.0, ctx->do_projection, stop);
 		}
 	}
 	HIPCHK(hipGetLastError());
@@ -2170,7 +2281,7 @@ int mchip_em_run(mchip_context *ctx, int slot, int n_steps, mchip_run_state *sta
 	int rc = check_slot(ctx, slot);
 	if (rc) return rc;
 	if (!state || n_steps < 1) return fail(ctx, MCHIP_ERR_INVALID, "em_run: bad arguments%s", nullptr);
-	if (ctx->qstride) ctx->empty_rows_nan = 1;	/* (set here too: a replayed graph does not pass through the enqueueing code) */
+	if (ctx->qstride) ctx->empty_rows_nan[slot] = 1;	/* (set here too: a replayed graph does not pass through the enqueueing code) */
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(ctx->d_run, state, sizeof *state, hipMemcpyHostToDevice, ctx->stream));
 	const int *stop = &ctx->d_run->stopped;
@@ -2213,7 +2324,7 @@ int mchip_em_step(mchip_context *ctx, int from, int to, double *loglik)
 	if ((rc = check_slot(ctx, to))) return rc;
 	HIPCHK(hipSetDevice(ctx->device));
 	if ((rc = run_estep(ctx, from, to, 1))) return rc;
-	if (ctx->qstride) ctx->empty_rows_nan = 1;
+	if (ctx->qstride) ctx->empty_rows_nan[to] = 1;
 	if (loglik) return fetch_scalars(ctx, 0, 1, loglik);
 	return MCHIP_OK;
 }
@@ -2284,7 +2395,8 @@ static int partition_finalize(mchip_context *ctx, int to, int counts, int n_asla
 	const int indiv = ctx->qstride != 0;
 	const int project = counts ? 0 : ctx->do_projection;
 	const double add = counts ? 1.0 : 0.0;
-	ctx->empty_rows_nan = 0;	/* initialize_parameters_admixture starts every count at 1 (rnd_init.c:624): 1 / K for such a row */
+	ctx->empty_rows_nan[to] = counts ? 0 : (ctx->qstride ? 1 : 0);	/* an M step of the hard partition: 0 / 0 for such a row (rnd_init.c:356); with counts
+									 * every count starts at 1 (rnd_init.c:624): 1 / K, as the device holds it */
 	ctx->kt->finalize_q(ctx->I, ctx->K, ctx->n_lchunks, ctx->d_Spart, ctx->d_q[to], ctx->qstride,
 			    ctx->d_q[to], ctx->d_sik, indiv, 0, project, ctx->eta_lb, nullptr, ctx->stream, add);
 	if (!indiv && (rc = finalize_shared_eta(ctx, to, nullptr, add, !counts))) return rc;
@@ -2603,6 +2715,7 @@ int mchip_copy_slot(mchip_context *ctx, int to, int from)
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(ctx->d_p[to], ctx->d_p[from], (size_t)ctx->K * ctx->T * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
 	HIPCHK(hipMemcpyAsync(ctx->d_q[to], ctx->d_q[from], (size_t)ctx->nq * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+	ctx->empty_rows_nan[to] = ctx->empty_rows_nan[from];
 	return MCHIP_OK;
 }
 
@@ -2813,6 +2926,7 @@ int mchip_accel_update(mchip_context *ctx, int to, int base, int j, double s, in
 	hipLaunchKernelGGL(k_accel_update, dim3(nblk(KT)), dim3(256), 0, ctx->stream, ctx->d_p[base], ctx->d_up[j], ctx->d_vp[j], ctx->d_p[to], KT, s, qn_form);
 	hipLaunchKernelGGL(k_accel_update, dim3(nblk(ctx->nq)), dim3(256), 0, ctx->stream, ctx->d_q[base], ctx->d_uq[j], ctx->d_vq[j], ctx->d_q[to], (size_t)ctx->nq, s, qn_form);
 	HIPCHK(hipGetLastError());
+	ctx->empty_rows_nan[to] = ctx->empty_rows_nan[base];	/* x + (anything of NaN secants) is NaN in the reference */
 	return project_slot(ctx, to);
 }
 
@@ -2901,7 +3015,7 @@ int mchip_accel_run(mchip_context *ctx, int slot, int scheme, int n_cycles, mchi
 	if (!state || n_cycles < 1 || scheme < 1 || scheme > 4) return fail(ctx, MCHIP_ERR_INVALID, "accel_run: bad arguments%s", nullptr);
 	if ((ctx->admixture && !ctx->sparse) || ctx->nsec < 1)
 		return fail(ctx, MCHIP_ERR_UNSUPPORTED, "accel_run: needs a secant pair; loci with more than 32 alleles run cycle by cycle%s", nullptr);
-	if (ctx->qstride) ctx->empty_rows_nan = 1;
+	if (ctx->qstride) ctx->empty_rows_nan[0] = ctx->empty_rows_nan[1] = ctx->empty_rows_nan[2] = 1;	/* every slot is written by the cycle's M steps */
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipMemcpyAsync(ctx->d_run, state, sizeof *state, hipMemcpyHostToDevice, ctx->stream));
 	/* does Spart hold the S-side sums of this very slot (mchip_loglik_prefetch, or the accepted cycle that ended the
@@ -2956,6 +3070,7 @@ int mchip_multisecant_update(mchip_context *ctx, int to, int base, int u_index, 
 		hipLaunchKernelGGL(k_axpy2, dim3(nblk(ctx->nq)), dim3(256), 0, ctx->stream, ctx->d_vq[v_index[t]], ctx->d_q[to], (size_t)ctx->nq, coef_a[t], coef_b[t]);
 	}
 	HIPCHK(hipGetLastError());
+	ctx->empty_rows_nan[to] = ctx->empty_rows_nan[base];
 	return project_slot(ctx, to);
 }
 

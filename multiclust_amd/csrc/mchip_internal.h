@@ -124,6 +124,8 @@ struct mchip_pass_args {
 	/* individual pass (lane = individual, loop over a chunk of loci) */
 	int lchunk, n_lchunks;	/* loci per chunk (multiple of 8) */
 	double *Spart;		/* [n_lchunks][I][K] sum_c P_kc r_ic over the chunk */
+	int xcd_rows;		/* the slab rows of the sparse cooperating kernel are a multiple of eight: workgroup id -> (tile, row) keeps a row
+				 * on one XCD */
 	int no_col_split;	/* MCHIP_NO_COL_SPLIT (experiments): one lane per allele column at every K */
 	int ind_waves;		/* sparse / biallelic individual passes: waves per workgroup; wave w takes sub-chunk w of lchunk loci of the
 				 * workgroup's ind_waves * lchunk loci, the slab index is blockIdx.y (mchip_ind_slabs() of them) */
@@ -176,13 +178,14 @@ const mchip_ktable *mchip_get_ktable(int K);
 
 inline int mchip_ind_waves(int K, int tile_cols)
 {
-	const size_t per_wave = (size_t)(K <= 12 ? 4 : 2) * (size_t)tile_cols * (size_t)mchip_kp(K) * sizeof(double);
+	/* (a buffer is rounded up to whole 1 KiB pieces where tiles are copied straight into LDS) */
+	const size_t per_wave = (size_t)(K <= 12 ? 4 : 2) * ((((size_t)tile_cols * (size_t)mchip_kp(K) + 127) / 128) * 128) * sizeof(double);
 	for (int w = MCHIP_IND_WAVES_MAX; w > 1; w >>= 1)
 		if ((size_t)w * per_wave <= 48 * 1024) return w;
 	return 1;
 }
 /* slabs (and partial log likelihoods per individual tile) the cooperating forms of the passes leave */
-inline int mchip_ind_slabs(const mchip_pass_args &a) { return (a.n_lchunks + a.ind_waves - 1) / a.ind_waves; }
-inline int mchip_col_slabs(const mchip_pass_args &a) { return (a.n_ichunks + MCHIP_COL_WAVES - 1) / MCHIP_COL_WAVES; }
+__host__ __device__ inline int mchip_ind_slabs(const mchip_pass_args &a) { return (a.n_lchunks + a.ind_waves - 1) / a.ind_waves; }
+__host__ __device__ inline int mchip_col_slabs(const mchip_pass_args &a) { return (a.n_ichunks + MCHIP_COL_WAVES - 1) / MCHIP_COL_WAVES; }
 
 #endif

@@ -412,7 +412,10 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts_split(mchip_pass_
 	const int i1 = min(a.I, i0 + a.ichunk);
 	const int g_end = (i1 + G - 1) / G;
 	/* the padding slots multiply p = 0: they must hold finite values, not whatever the last kernel left in LDS */
-	for (int x = threadIdx.x; x < 2 * PERWORD * ROW; x += MCHIP_BLOCK) qs[0][x] = 0.0;
+	{
+		double *flat = &qs[0][0];	/* both buffers, as the one array they are */
+		for (int x = threadIdx.x; x < 2 * PERWORD * ROW; x += MCHIP_BLOCK) flat[x] = 0.0;
+	}
 	__syncthreads();
 	auto q_address = [&](int x, int ibase) __attribute__((always_inline)) {	/* element x of a batch: individual x / K, cluster x % K */
 		const int j = x / K, k = x % K;
@@ -960,9 +963,14 @@ __global__ __launch_bounds__(64 * MCHIP_IND_WAVES_MAX) void k_individual_sparse_
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int W = a.ind_waves;
+	/* which (tile of 64 individuals, slab row) this workgroup is: coop_rows() */
+	const int n_tiles = (a.I + 63) / 64, n_rows = mchip_ind_slabs(a);
+	const int slot = a.xcd_rows ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+	const int bx = slot % n_tiles, by = a.xcd_rows ? (slot / n_tiles) * 8 + (int)(blockIdx.x & 7) : slot / n_tiles;
+	(void)n_rows;
 	const size_t tile_doubles = tile_stride(a.tile_cols);
 	double *mine = lds + (size_t)wv * 2 * SETS * tile_doubles;
-	const int i_raw = blockIdx.x * 64 + lane;
+	const int i_raw = bx * 64 + lane;
 	const bool active = i_raw < a.I;
 	const int i = active ? i_raw : a.I - 1;
 	const int pl = PL ? PL : a.ploidy;
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(64 * MCHIP_IND_WAVES_MAX) void k_individual_sparse_
 		acc[k] = 0.0;
 		if constexpr (DUAL) q2[k] = a.Q2[(size_t)i * a.qstride + k];
 	}
-	const int l0 = (blockIdx.y * W + wv) * a.lchunk;
+	const int l0 = (by * W + wv) * a.lchunk;
 	const int l1 = min(a.L, l0 + a.lchunk);
 	double prod = 1.0, prod2 = 1.0;
 	int blk = 0, ex = 0, ex2 = 0;
@@ -1221,15 +1229,15 @@ __global__ __launch_bounds__(64 * MCHIP_IND_WAVES_MAX) void k_individual_sparse_
 	}
 	if (wv == 0) {
 		if (ACCUM && active) {
-			double *out = a.Spart + ((size_t)blockIdx.y * a.I + i) * K;
+			double *out = a.Spart + ((size_t)by * a.I + i) * K;
 #pragma unroll
 			for (int k = 0; k < K; k++) out[k] = acc[k];
 		}
 		const double tot = wave_total(active ? ll : 0.0);
-		if (lane == 0) a.llpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+		if (lane == 0) a.llpart[(size_t)by * n_tiles + bx] = tot;
 		if (DUAL) {
 			const double tot2 = wave_total(active ? ll2 : 0.0);
-			if (lane == 0) a.llpart2[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot2;
+			if (lane == 0) a.llpart2[(size_t)by * n_tiles + bx] = tot2;
 		}
 	}
 }
@@ -1615,20 +1623,70 @@ __device__ __forceinline__ void michelot_k(double (&x)[K], double mn)
 
 /* Q[to][i][.] = normalise(q_ik * sum_chunks Spart) then project (em_alg.c:685-701); also stores the
  * expected counts S_ik the writers need (write_file.c:359-381). */
+constexpr int FQ_LANES = 8, FQ_IND = MCHIP_BLOCK / FQ_LANES;	/* threads per individual / individuals per block of k_finalize_q */
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_q(int I, int n_lchunks, const double *__restrict__ Spart,
 		const double *__restrict__ Qfrom, int qstride_from, double *Qto, double *sik,
 		int do_mstep, int weighted, int do_projection, double lb, const int *stop, double add)
 {
-	const int i = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
-	if (i >= I || (stop && *stop)) return;
+	/* FQ_IND individuals per block, FQ_LANES threads each: thread g of an individual adds slabs g, g + 8, ... (four loads in
+	 * flight at a time), the partial sums meet in LDS in the order g = 0 .. 7, and thread 0 of the individual carries on.  Every
+	 * slab count is handled here: there is no separate slab-sum launch in front (k_sum_slabs took this scheme's place) */
+	constexpr int TURNS = K <= 16 ? 1 : FQ_LANES - 1;	/* K <= 16: all partial sums at once (28 KB of LDS at most); above: in turns */
+	__shared__ double xch[K <= 16 ? FQ_LANES - 1 : 1][K][FQ_IND];
+	if (stop && *stop) return;		/* (uniform over the grid) */
+	const int il = threadIdx.x % FQ_IND, g = threadIdx.x / FQ_IND;
+	const int i = blockIdx.x * FQ_IND + il;
+	const bool active = i < I;
 	double s[K];
 #pragma unroll
 	for (int k = 0; k < K; k++) s[k] = 0.0;
-	for (int ch = 0; ch < n_lchunks; ch++) {
-		const double *src = Spart + ((size_t)ch * I + i) * K;
+	if (active) {
+		const size_t row = (size_t)I * K;
+		const double *src = Spart + (size_t)g * row + (size_t)i * K;
+		int ch = g;
+		for (; ch + 3 * FQ_LANES < n_lchunks; ch += 4 * FQ_LANES, src += 4 * FQ_LANES * row) {
+			double v[4][K];
 #pragma unroll
-		for (int k = 0; k < K; k++) s[k] += src[k];
+			for (int y = 0; y < 4; y++)
+#pragma unroll
+				for (int k = 0; k < K; k++) v[y][k] = src[(size_t)y * FQ_LANES * row + k];
+#pragma unroll
+			for (int y = 0; y < 4; y++)
+#pragma unroll
+				for (int k = 0; k < K; k++) s[k] += v[y][k];
+		}
+		for (; ch < n_lchunks; ch += FQ_LANES, src += FQ_LANES * row) {
+#pragma unroll
+			for (int k = 0; k < K; k++) s[k] += src[k];
+		}
 	}
+	if constexpr (TURNS == 1) {
+		if (g) {
+#pragma unroll
+			for (int k = 0; k < K; k++) xch[g - 1][k][il] = s[k];
+		}
+		__syncthreads();
+		if (g == 0) {
+#pragma unroll
+			for (int x = 0; x < FQ_LANES - 1; x++)
+#pragma unroll
+				for (int k = 0; k < K; k++) s[k] += xch[x][k][il];
+		}
+	} else {
+		for (int x = 1; x < FQ_LANES; x++) {
+			if (g == x) {
+#pragma unroll
+				for (int k = 0; k < K; k++) xch[0][k][il] = s[k];
+			}
+			__syncthreads();
+			if (g == 0) {
+#pragma unroll
+				for (int k = 0; k < K; k++) s[k] += xch[0][k][il];
+			}
+			__syncthreads();
+		}
+	}
+	if (g || !active) return;
 	if (weighted) {
 #pragma unroll
 		for (int k = 0; k < K; k++) s[k] *= Qfrom[(size_t)i * qstride_from + k];
@@ -1677,6 +1735,13 @@ inline dim3 indiv_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK - 1
 inline dim3 sparse_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK / SPLIT - 1) / (QBLOCK / SPLIT), a.n_lchunks); }
 /* the cooperating forms (K <= 27): 64 individuals per workgroup, a.ind_waves waves, one slab per workgroup row */
 inline dim3 coop_grid(const mchip_pass_args &a) { return dim3((a.I + 63) / 64, mchip_ind_slabs(a)); }
+/* The sparse kernel takes a one-dimensional grid and works out (tile, row) itself.  Consecutive workgroup ids go to consecutive
+ * XCDs (eight of them, each with its own L2), and every workgroup of a slab row reads the same P rows: with id -> (id / 8 mod
+ * tiles, id / 8 / tiles * 8 + id mod 8) a row lives on ONE XCD and its P rows come into one L2 instead of eight (154 MB less
+ * fabric traffic per pass at config 3; the pass is not bandwidth-bound, so this is about bytes, not time).  Only where the rows
+ * come in whole groups of eight (a.xcd_rows; mchip_set_model rounds the chunk count for that): with 52 rows four XCDs would have
+ * seven rows and four six, and the pass ran 5 % longer than with the plain order. */
+inline dim3 coop_rows(const mchip_pass_args &a) { return dim3((unsigned)(((a.I + 63) / 64) * mchip_ind_slabs(a))); }
 inline size_t coop_lds_bytes(const mchip_pass_args &a, int sets)
 {
 	const size_t tiles = (size_t)a.ind_waves * 2 * sets * tile_stride(a.tile_cols), hand_over = (size_t)(K + 2) * 64;
@@ -1726,7 +1791,7 @@ template <bool ACCUM> void launch_sparse(const mchip_pass_args &a, hipStream_t s
 	 * form costs more instructions per locus: +8-19 % below that) */
 	constexpr bool bial_pays = SPLIT == 1 && (ACCUM ? (K >= 10) : (K >= 6));	/* (its grid and partials are one lane per individual) */
 	if constexpr (SPLIT == 1) {
-		const dim3 grid = coop_grid(a), block(64 * a.ind_waves);
+		const dim3 grid = coop_grid(a), rows = coop_rows(a), block(64 * a.ind_waves);
 		const size_t cl = coop_lds_bytes(a, 1);
 		if (bial_pays && a.biallelic && a.ploidy == 2 && !safe) {
 			if (nomiss) hipLaunchKernelGGL((k_individual_bial<ACCUM, true>), grid, block, 0, s, a);
@@ -1735,13 +1800,13 @@ template <bool ACCUM> void launch_sparse(const mchip_pass_args &a, hipStream_t s
 		}
 #define MCHIP_SPARSE_W(PLV) \
 		do { \
-			if (nomiss && !safe) hipLaunchKernelGGL((k_individual_sparse_w<PLV, ACCUM, false, true>), grid, block, cl, s, a); \
-			else if (!safe) hipLaunchKernelGGL((k_individual_sparse_w<PLV, ACCUM, false, false>), grid, block, cl, s, a); \
-			else hipLaunchKernelGGL((k_individual_sparse_w<PLV, ACCUM, true, false>), grid, block, cl, s, a); \
+			if (nomiss && !safe) hipLaunchKernelGGL((k_individual_sparse_w<PLV, ACCUM, false, true>), rows, block, cl, s, a); \
+			else if (!safe) hipLaunchKernelGGL((k_individual_sparse_w<PLV, ACCUM, false, false>), rows, block, cl, s, a); \
+			else hipLaunchKernelGGL((k_individual_sparse_w<PLV, ACCUM, true, false>), rows, block, cl, s, a); \
 		} while (0)
 		if (a.ploidy == 2) MCHIP_SPARSE_W(2);
 		else if (a.ploidy == 4) MCHIP_SPARSE_W(4);
-		else hipLaunchKernelGGL((k_individual_sparse_w<0, ACCUM, true, false>), grid, block, cl, s, a);
+		else hipLaunchKernelGGL((k_individual_sparse_w<0, ACCUM, true, false>), rows, block, cl, s, a);
 #undef MCHIP_SPARSE_W
 	} else {
 #define MCHIP_SPARSE(PLV) \
@@ -1768,8 +1833,8 @@ void launch_accum_q_dual(const mchip_pass_args &a, hipStream_t s)
 {
 	if constexpr (K <= 12) {
 		const size_t lds = coop_lds_bytes(a, 2);
-		if (!a.has_missing) hipLaunchKernelGGL((k_individual_sparse_w<2, true, false, true, true>), coop_grid(a), dim3(64 * a.ind_waves), lds, s, a);
-		else hipLaunchKernelGGL((k_individual_sparse_w<2, true, false, false, true>), coop_grid(a), dim3(64 * a.ind_waves), lds, s, a);
+		if (!a.has_missing) hipLaunchKernelGGL((k_individual_sparse_w<2, true, false, true, true>), coop_rows(a), dim3(64 * a.ind_waves), lds, s, a);
+		else hipLaunchKernelGGL((k_individual_sparse_w<2, true, false, false, true>), coop_rows(a), dim3(64 * a.ind_waves), lds, s, a);
 	}
 }
 /* what the launchers leave behind (mchip_ktable) */
@@ -1836,7 +1901,7 @@ void launch_finalize_q(int I, int, int n_lchunks, const double *Spart, const dou
 		       double *Qto, double *sik, int do_mstep, int weighted, int do_projection, double lb, const int *stop, hipStream_t s,
 		       double add)
 {
-	hipLaunchKernelGGL(k_finalize_q, dim3((I + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s,
+	hipLaunchKernelGGL(k_finalize_q, dim3((I + FQ_IND - 1) / FQ_IND), dim3(MCHIP_BLOCK), 0, s,
 			   I, n_lchunks, Spart, Qfrom, qstride_from, Qto, sik, do_mstep, weighted, do_projection, lb, stop, add);
 }
 void launch_project_q(int nrows, int, double *Q, double lb, const int *stop, hipStream_t s)

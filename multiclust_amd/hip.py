@@ -92,9 +92,9 @@ def load():
         "mchip_progress_note": ([C.c_char_p], i32),
     }
     for name, (args, res) in sig.items():
-        if "MCHIP_LIB_PATH" in os.environ and not hasattr(lib, name):
-            continue                   # an older experimental build under comparison (scripts/diag/bits.sh); the product library
-        fn = getattr(lib, name)        # AttributeError here = the library does not export its own header
+        if os.environ.get("MCHIP_ALLOW_PARTIAL_ABI") == "1" and not hasattr(lib, name):
+            continue                   # diagnostics only (scripts/diag/bits.sh: an older build under comparison); MCHIP_LIB_PATH alone
+        fn = getattr(lib, name)        # keeps the strict check: AttributeError here = the library does not export its own header
         fn.argtypes = args
         fn.restype = res
     _lib = lib

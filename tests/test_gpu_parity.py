@@ -441,3 +441,36 @@ def test_mixture_loglik_without_an_ordinary_term_is_nan_not_a_stall(ctx, poison)
     assert np.isnan(ll)
     ctx.set_p(0, p0)
     assert ctx.loglik(0) == good                                  # the stream came back, and with the same bits
+
+
+def test_rows_of_individuals_without_copies_are_reported_per_slot_and_survive_a_round_trip(ctx):
+    """An individual without a single observed copy has mixing proportions 0 / 0 = NaN in the reference from its first M step on
+    (em_alg.c:685-690); the device holds a finite row and mchip_get_q reports NaN for the SLOTS that stand for it -- the slot an M
+    step wrote, not the one it read -- and mchip_set_q takes such a row back (warm start, checkpoint): the NaN is stored as the
+    finite row, the slot goes on reporting NaN, and nothing it is multiplied into turns NaN."""
+    I, L, K = 60, 80, 3
+    ua, geno = make_dataset(I, L, K, ploidy=2, max_alleles=3, seed=9)
+    geno[7] = 0xFF
+    lb = ob.lib.mco_lower_bound(1e-8, I, 2)
+    q0, p0 = random_params(I, ua, K, seed=4, lower_bound=lb)
+    ctx.set_genotypes(ua, geno)
+    ctx.set_model(K, lower_bound=lb)
+    ctx.set_q(0, q0)
+    ctx.set_p(0, p0)
+    ll = ctx.em_step(0, 1)                                  # E step on slot 0, M step into slot 1
+    assert np.isfinite(ll)
+    q1 = ctx.get_q(1)
+    assert np.isnan(q1[7]).all() and np.isfinite(np.delete(q1, 7, axis=0)).all()
+    assert np.array_equal(ctx.get_q(0), q0)                 # the slot the step read still holds what the caller put there
+    ctx.set_q(2, q1)                                        # the round trip: a NaN row goes back in
+    ctx.set_p(2, ctx.get_p(1))
+    assert np.isnan(ctx.get_q(2)[7]).all()
+    ll2 = ctx.em_step(2, 2)
+    p2, q2 = ctx.get_p(2), ctx.get_q(2)
+    assert np.isfinite(ll2) and np.isfinite(p2).all() and np.isnan(q2[7]).all() and np.isfinite(np.delete(q2, 7, axis=0)).all()
+    ll1 = ctx.em_step(1, 1)                                 # the same step without the round trip: same bits
+    assert ll1 == ll2 and np.array_equal(ctx.get_p(1), p2)
+    finite = q1.copy()
+    finite[7] = 1.0 / K
+    ctx.set_q(2, finite)                                    # a finite row is stored and reported as given
+    assert np.array_equal(ctx.get_q(2), finite)
