@@ -115,7 +115,7 @@ struct mchip_context {
 	 * model -- never on a launch path */
 	struct {
 		int no_bial, no_counts, force_dense, force_safe, no_graph, no_dual, no_slab_sum, no_col_split, part_no_tile, sim_no_tile;
-		int per_cu_col, per_cu_ind, geometry_given;
+		int per_cu_col, per_cu_ind, geometry_given, no_roundup;
 		double slab_frac;
 	} knob;
 	double *d_Apart, *d_Spart, *d_llpart, *d_scalars;	/* d_scalars: [0]=logL, [1..3]=dots, [4..]=eta sums */
@@ -157,6 +157,7 @@ static void read_knobs(mchip_context *ctx)
 	ctx->knob.per_cu_ind = num("MCHIP_BLOCKS_PER_CU_IND", both);
 	const char *f = getenv("MCHIP_SLAB_FRAC");
 	ctx->knob.slab_frac = (f && atof(f) > 0) ? atof(f) : 0.3;
+	ctx->knob.no_roundup = on("MCHIP_NO_CHUNK_ROUNDUP");
 	ctx->knob.geometry_given = on("MCHIP_BLOCKS_PER_CU") || on("MCHIP_BLOCKS_PER_CU_COL") || on("MCHIP_SLAB_FRAC");
 }
 
@@ -1981,7 +1982,7 @@ static int set_model_impl(mchip_context *ctx, int K, int admixture, int eta_cons
 	if (want > cap) want = cap;
 	if (want < 1) want = 1;
 	if (want > iblocks) want = iblocks;
-	if (ctx->count_bits) {	/* the packed-count column pass puts MCHIP_COL_WAVES chunks into a workgroup: whole workgroups where the caps allow */
+	if (ctx->count_bits && !ctx->knob.no_roundup) {	/* the packed-count column pass puts MCHIP_COL_WAVES chunks into a workgroup: whole workgroups where the caps allow */
 		const int up = ((want + MCHIP_COL_WAVES - 1) / MCHIP_COL_WAVES) * MCHIP_COL_WAVES;
 		if (up <= cap && up <= iblocks) want = up;
 	}
