@@ -273,15 +273,8 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 	/* the workgroup's MCHIP_COL_WAVES waves take the same 64 allele columns and consecutive sub-chunks of a.ichunk individuals;
 	 * their sums meet in LDS below, in wave order, and wave 0 stores the slab (mchip_internal.h: cooperating waves) */
 	__shared__ double wsum[K][64];
-#ifdef MCHIP_EXP_COL_R3
-	/* EXPERIMENT (never in the product build; the host expects a quarter of the slabs): round 3's division of labour -- 256
-	 * columns per workgroup, every wave the workgroup's whole chunk, one slab per chunk -- with everything else as it is now */
-	const int lane = threadIdx.x & 63, wv = 0;
-	const int c_raw = blockIdx.x * MCHIP_BLOCK + threadIdx.x;
-#else
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;	/* wv is wave-uniform */
 	const int c_raw = blockIdx.x * 64 + lane;
-#endif
 	const bool valid = c_raw < a.T;
 	const int c = valid ? c_raw : a.T - 1;
 	double p[K], acc[K];
@@ -290,15 +283,7 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 		p[k] = MIX ? 0.0 : a.P[(size_t)c * K + k];
 		acc[k] = 0.0;
 	}
-#if defined(MCHIP_EXP_COL_R3)
-	const int i0 = blockIdx.y * a.ichunk;
-#elif defined(MCHIP_EXP_SAME_CHUNK)
-	/* EXPERIMENT (never in the product build; wrong sums): the four waves of a workgroup walk the SAME individuals, i.e. the same
-	 * q rows through the scalar cache, as the waves of a round-3 workgroup did: what the four separate row streams cost */
-	const int i0 = __builtin_amdgcn_readfirstlane((blockIdx.y * MCHIP_COL_WAVES + 0 * wv) * a.ichunk);
-#else
 	const int i0 = __builtin_amdgcn_readfirstlane((blockIdx.y * MCHIP_COL_WAVES + wv) * a.ichunk);	/* multiple of G */
-#endif
 	const int i1 = min(a.I, i0 + a.ichunk);
 	const int g_end = (i1 + G - 1) / G;		/* (a wave whose sub-chunk starts behind the last individual has no groups) */
 	const uint4 *gt = reinterpret_cast<const uint4 *>(a.gtC);
@@ -348,15 +333,6 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_column_counts(mchip_pass_args a
 		}
 		w = wn;
 	}
-#ifdef MCHIP_EXP_COL_R3
-	(void)lane; (void)wsum;
-	if (valid) {
-		double *out = a.Apart + ((size_t)blockIdx.y * a.T + c) * K;
-#pragma unroll
-		for (int k = 0; k < K; k++) out[k] = acc[k];
-	}
-	return;
-#endif
 	/* (lane, wave and column are worked out again from the thread index, laundered so that hipcc does not keep the first copies
 	 * alive across the loop: those four registers were the difference between 7 and 6 waves per SIMD at K = 8) */
 	unsigned tid = threadIdx.x;
@@ -1754,11 +1730,7 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_project_q(int nrows, double *Q,
 /* ---------------------------------------------------------------- launchers */
 inline dim3 column_grid(const mchip_pass_args &a) { return dim3((a.T + MCHIP_BLOCK - 1) / MCHIP_BLOCK, a.n_ichunks); }
 /* packed-count column pass (cooperating waves): 64 columns per workgroup, one slab per workgroup row */
-#ifdef MCHIP_EXP_COL_R3
-inline dim3 counts_grid(const mchip_pass_args &a) { return dim3((a.T + MCHIP_BLOCK - 1) / MCHIP_BLOCK, a.n_ichunks); }
-#else
 inline dim3 counts_grid(const mchip_pass_args &a) { return dim3((a.T + 63) / 64, mchip_col_slabs(a)); }
-#endif
 inline dim3 indiv_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK - 1) / QBLOCK, a.n_lchunks); }
 inline dim3 sparse_grid(const mchip_pass_args &a) { return dim3((a.I + QBLOCK / SPLIT - 1) / (QBLOCK / SPLIT), a.n_lchunks); }
 /* the cooperating forms (K <= 27): 64 individuals per workgroup, a.ind_waves waves, one slab per workgroup row */
