@@ -114,7 +114,7 @@ struct mchip_context {
 	/* testing / tuning knobs of the environment (README), read when a context is created and again with every data set and every
 	 * model -- never on a launch path */
 	struct {
-		int no_bial, no_counts, force_dense, force_safe, no_graph, no_dual, dual_fused, no_slab_sum, no_col_split, part_no_tile, sim_no_tile;
+		int no_bial, no_counts, force_dense, force_safe, no_graph, no_dual, no_slab_sum, no_col_split, part_no_tile, sim_no_tile;
 		int per_cu_col, per_cu_ind, geometry_given, no_roundup;
 		double slab_frac;
 	} knob;
@@ -148,7 +148,6 @@ static void read_knobs(mchip_context *ctx)
 	ctx->knob.force_safe = on("MCHIP_FORCE_SAFE");
 	ctx->knob.no_graph = on("MCHIP_NO_GRAPH");
 	ctx->knob.no_dual = on("MCHIP_NO_DUAL");
-	ctx->knob.dual_fused = on("MCHIP_DUAL_FUSED");
 	ctx->knob.no_slab_sum = on("MCHIP_NO_SLAB_SUM");
 	ctx->knob.no_col_split = on("MCHIP_NO_COL_SPLIT");
 	ctx->knob.part_no_tile = on("MCHIP_PART_NO_TILE");
@@ -2956,13 +2955,7 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 	dual.P2 = ctx->d_p[C];
 	dual.Q2 = ctx->d_q[C];
 	dual.llpart2 = ctx->d_llpart2;
-	/* ... in one of two forms: the paired grid (workgroups of the S-side pass of B and of the log-likelihood pass of C alternate in
-	 * one launch), or -- MCHIP_DUAL_FUSED, and where the pair is not available -- round 2's dual instance (every lane does both) */
-	mchip_pass_args pair_ll = pass_args(ctx, C);
-	pair_ll.stop = stop;
-	pair_ll.llpart = ctx->d_llpart2;
-	const bool use_pair = ctx->admixture && !ctx->knob.no_dual && !ctx->knob.dual_fused && ctx->kt->pair_available(dual);
-	const bool use_dual = use_pair || (ctx->admixture && !ctx->knob.no_dual && ctx->kt->dual_available(dual));
+	const bool use_dual = ctx->admixture && !ctx->knob.no_dual && ctx->kt->dual_available(dual);
 	if (!ctx->admixture) {
 		if ((rc = run_mixture(ctx, C, C, 0, 1, stop, 1))) return rc;	/* logL_mixture */
 	} else if (!use_dual) {
@@ -2993,8 +2986,7 @@ static int accel_cycle_enqueue(mchip_context *ctx, int A, int scheme)
 	} else {
 		if (use_dual) {
 			prof_mark(ctx, MCHIP_KERN_DUAL, true);
-			if (use_pair) ctx->kt->accum_q_pair(dual, pair_ll, ctx->stream);
-			else ctx->kt->accum_q_dual(dual, ctx->stream);
+			ctx->kt->accum_q_dual(dual, ctx->stream);
 			prof_mark(ctx, MCHIP_KERN_DUAL, false);
 		} else {
 			mchip_pass_args a = pass_args(ctx, B);

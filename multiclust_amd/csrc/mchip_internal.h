@@ -172,10 +172,6 @@ struct mchip_ktable {
 	int (*col_slabs)(const mchip_pass_args &a, int mix);
 	int (*ind_slabs)(const mchip_pass_args &a);
 	int (*ind_ll_parts)(const mchip_pass_args &a);
-	/* individual pass of a (S-side sums + log L -> a.Spart, a.llpart) and stand-alone log-likelihood pass of b (-> b.llpart) as ONE
-	 * grid whose workgroups alternate between the two, where pair_available() says so: the results of the two separate launches */
-	int (*pair_available)(const mchip_pass_args &a);
-	void (*accum_q_pair)(const mchip_pass_args &a, const mchip_pass_args &b, hipStream_t s);
 };
 
 const mchip_ktable *mchip_get_ktable(int K);

@@ -952,7 +952,7 @@ __device__ __forceinline__ void glds_wait()
 }
 
 template <int PL, bool ACCUM, bool SAFE, bool NOMISS, bool DUAL = false>
-__device__ __forceinline__ void sparse_w_body(const mchip_pass_args &a, const unsigned wg)	/* wg: which workgroup of the pass this is */
+__global__ __launch_bounds__(64 * MCHIP_IND_WAVES_MAX) void k_individual_sparse_w(mchip_pass_args a)
 {
 	static_assert(SPLIT == 1, "wave-private tiles: one lane per individual");
 	static_assert(!DUAL || (ACCUM && !SAFE && PL == 2), "dual pass: ACCUM, shared reciprocals, diploid");
@@ -965,9 +965,9 @@ __device__ __forceinline__ void sparse_w_body(const mchip_pass_args &a, const un
 	const int W = a.ind_waves;
 	/* which (tile of 64 individuals, slab row) this workgroup is: coop_rows() */
 	const int n_tiles = (a.I + 63) / 64, n_rows = mchip_ind_slabs(a);
-	const int slot = a.xcd_rows ? (int)(wg >> 3) : (int)wg;
-	const int bx = slot % n_tiles, by = a.xcd_rows ? (slot / n_tiles) * 8 + (int)(wg & 7) : slot / n_tiles;
-	if (by >= n_rows) return;		/* (the paired grid is padded to whole groups of eight; uniform over the workgroup) */
+	const int slot = a.xcd_rows ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+	const int bx = slot % n_tiles, by = a.xcd_rows ? (slot / n_tiles) * 8 + (int)(blockIdx.x & 7) : slot / n_tiles;
+	(void)n_rows;
 	const size_t tile_doubles = tile_stride(a.tile_cols);
 	double *mine = lds + (size_t)wv * 2 * SETS * tile_doubles;
 	const int i_raw = bx * 64 + lane;
@@ -1240,28 +1240,6 @@ __device__ __forceinline__ void sparse_w_body(const mchip_pass_args &a, const un
 			if (lane == 0) a.llpart2[(size_t)by * n_tiles + bx] = tot2;
 		}
 	}
-}
-
-template <int PL, bool ACCUM, bool SAFE, bool NOMISS, bool DUAL = false>
-__global__ __launch_bounds__(64 * MCHIP_IND_WAVES_MAX) void k_individual_sparse_w(mchip_pass_args a)
-{
-	sparse_w_body<PL, ACCUM, SAFE, NOMISS, DUAL>(a, blockIdx.x);
-}
-
-/* Two passes in one grid: the S-side pass of one parameter set (a) and the stand-alone log-likelihood pass of another (b) -- what
- * an accelerated cycle needs back to back: the E step of the extrapolated point and log L of the second EM iterate
- * (accel_em.c:53,544).  The first is bound by FP64 issue, the second by the LDS gather; as two launches, even on two streams,
- * their workgroups never share a compute unit (the second grid gets the units the first one leaves, docs/DESIGN_r3.md 4.3).  Here
- * the grid alternates eight workgroups of one kind with eight of the other (eight: consecutive ids go to the eight XCDs, and
- * wg -> (tile, row) keeps a row on one of them), so both kinds are resident on every unit at any time and the two bottlenecks
- * overlap across waves.  Each kind runs the very code of its own kernel: the results are those of the two separate passes,
- * bit for bit. */
-template <int PL, bool NOMISS>
-__global__ __launch_bounds__(64 * MCHIP_IND_WAVES_MAX) void k_individual_pair(mchip_pass_args a, mchip_pass_args b)
-{
-	const unsigned wg = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7u);
-	if ((blockIdx.x >> 3) & 1u) sparse_w_body<PL, false, false, NOMISS>(b, wg);
-	else sparse_w_body<PL, true, false, NOMISS>(a, wg);
 }
 
 /* ---------------------------------------------------------------- individual pass, every locus biallelic (SNP data)
@@ -1859,27 +1837,6 @@ void launch_accum_q_dual(const mchip_pass_args &a, hipStream_t s)
 		else hipLaunchKernelGGL((k_individual_sparse_w<2, true, false, false, true>), coop_rows(a), dim3(64 * a.ind_waves), lds, s, a);
 	}
 }
-/* the paired grid (k_individual_pair): available where both halves would run the sparse cooperating kernel with shared reciprocals */
-int pair_available(const mchip_pass_args &a)
-{
-	if (SPLIT != 1 || !a.sparse || a.flush_blocks < 1 || (a.ploidy != 2 && a.ploidy != 4)) return 0;
-	constexpr bool bial_s = K >= 10, bial_l = K >= 6;	/* launch_sparse's thresholds for k_individual_bial */
-	if (a.biallelic && a.ploidy == 2 && (bial_s || bial_l)) return 0;
-	return 1;
-}
-void launch_accum_q_pair(const mchip_pass_args &a, const mchip_pass_args &b, hipStream_t s)
-{
-	if constexpr (SPLIT == 1) {
-		const unsigned n_wg = coop_rows(a).x, grid = ((n_wg + 7) / 8) * 16;
-		const dim3 block(64 * a.ind_waves);
-		const size_t lds = coop_lds_bytes(a, 1);
-		const bool nomiss = !a.has_missing;
-		if (a.ploidy == 2 && nomiss) hipLaunchKernelGGL((k_individual_pair<2, true>), dim3(grid), block, lds, s, a, b);
-		else if (a.ploidy == 2) hipLaunchKernelGGL((k_individual_pair<2, false>), dim3(grid), block, lds, s, a, b);
-		else if (nomiss) hipLaunchKernelGGL((k_individual_pair<4, true>), dim3(grid), block, lds, s, a, b);
-		else hipLaunchKernelGGL((k_individual_pair<4, false>), dim3(grid), block, lds, s, a, b);
-	}
-}
 /* what the launchers leave behind (mchip_ktable) */
 int col_slabs(const mchip_pass_args &a, int mix)
 {
@@ -1962,7 +1919,7 @@ const mchip_ktable *MCHIP_CAT(mchip_ktable_get_, MCHIP_K)()
 	static mchip_ktable t = {
 		launch_accum_p, launch_loglik, launch_accum_q, launch_part_p, launch_part_q, launch_finalize_q, launch_project_q,
 		launch_mix_gather, launch_mix_finalize, launch_mix_column, dual_available, launch_accum_q_dual,
-		col_slabs, ind_slabs, ind_ll_parts, pair_available, launch_accum_q_pair,
+		col_slabs, ind_slabs, ind_ll_parts,
 	};
 	return &t;
 }

@@ -425,10 +425,8 @@ def test_dual_individual_pass_equals_the_two_passes(K, maxal, missing, scheme, m
     from synth import make_dataset
     ua, geno = make_dataset(300, 700, K, ploidy=2, max_alleles=maxal, seed=77 + K, missing=missing)
     out = []
-    # default: the paired grid (S-side pass and log-likelihood pass as alternating workgroups of one launch); MCHIP_DUAL_FUSED: every
-    # lane does both (round 2's instance); MCHIP_NO_DUAL: two launches; MC_NO_BATCH: the cycle driven call by call from the host
-    for env in ({}, {"MCHIP_DUAL_FUSED": "1"}, {"MCHIP_NO_DUAL": "1"}, {"MC_NO_BATCH": "1"}):
-        for k in ("MCHIP_NO_DUAL", "MCHIP_DUAL_FUSED", "MC_NO_BATCH"):
+    for env in ({}, {"MCHIP_NO_DUAL": "1"}, {"MC_NO_BATCH": "1"}):
+        for k in ("MCHIP_NO_DUAL", "MC_NO_BATCH"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
