@@ -21,11 +21,11 @@ all: $(LIB)/libmulticlust_hip.so $(LIB)/libmulticlust_host.so $(BIN)/multiclust 
 # With the flag tuples spill to scratch whole.  Only kernels that use the whole register file spill (K > 20); applied to every
 # translation unit all the same.  Reproducer: `make exp-k52`, scripts/diag/k52_spill.sh.
 KFLAGS = -mllvm -amdgpu-spill-vgpr-to-agpr=false
-$(OBJ)/mchip_k%.o: multiclust_amd/csrc/mchip_kernels_k.hip multiclust_amd/csrc/mchip_internal.h include/multiclust_hip.h
+$(OBJ)/mchip_k%.o: multiclust_amd/csrc/mchip_kernels_k.hip multiclust_amd/csrc/mchip_internal.h multiclust_amd/csrc/mchip_finalize.h include/multiclust_hip.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -DMCHIP_K=$* -c $< -o $@
 
-$(OBJ)/mchip.o: multiclust_amd/csrc/mchip.hip multiclust_amd/csrc/mchip_internal.h multiclust_amd/csrc/mchip_progress.h include/multiclust_hip.h
+$(OBJ)/mchip.o: multiclust_amd/csrc/mchip.hip multiclust_amd/csrc/mchip_internal.h multiclust_amd/csrc/mchip_finalize.h multiclust_amd/csrc/mchip_progress.h include/multiclust_hip.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -c $< -o $@
 

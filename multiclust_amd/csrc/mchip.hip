@@ -4,6 +4,7 @@
  * fails with MCHIP_ERR_NO_DEVICE / MCHIP_ERR_HIP when the GPU path cannot run.
  */
 #include "mchip_internal.h"
+#include "mchip_finalize.h"
 #include "mchip_progress.h"
 
 #include <math.h>
@@ -115,6 +116,7 @@ struct mchip_context {
 	 * model -- never on a launch path */
 	struct {
 		int no_bial, no_counts, force_dense, force_safe, no_graph, no_dual, no_slab_sum, no_col_split, part_no_tile, sim_no_tile;
+		int no_fused_finalize;
 		int per_cu_col, per_cu_ind, geometry_given, no_roundup;
 		double slab_frac;
 	} knob;
@@ -149,6 +151,7 @@ static void read_knobs(mchip_context *ctx)
 	ctx->knob.no_graph = on("MCHIP_NO_GRAPH");
 	ctx->knob.no_dual = on("MCHIP_NO_DUAL");
 	ctx->knob.no_slab_sum = on("MCHIP_NO_SLAB_SUM");
+	ctx->knob.no_fused_finalize = on("MCHIP_NO_FUSED_FINALIZE");
 	ctx->knob.no_col_split = on("MCHIP_NO_COL_SPLIT");
 	ctx->knob.part_no_tile = on("MCHIP_PART_NO_TILE");
 	ctx->knob.sim_no_tile = on("MCHIP_SIM_NO_TILE");
@@ -962,62 +965,6 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_sum_slabs(const double *__restr
 	}
 }
 
-/* simplex.c:109-143 on a strided vector in memory; fixed-entry set kept in a 64-bit mask (len <= 64)
- * or in byte flags (longer) */
-__device__ void michelot_strided(double *x, int stride, int len, double mn, uint8_t *flags)
-{
-	unsigned long long fixed = 0ull;
-	int n = len;
-	if (len > 64) for (int j = 0; j < len; j++) flags[(size_t)j * stride] = 0;
-	while (n) {
-		double csum = 0.0;
-		for (int j = 0; j < len; j++) csum += x[(size_t)j * stride];
-		const double shift = (csum - 1.0) / (double)n;
-		bool can_terminate = true;
-		for (int j = 0; j < len; j++) {
-			const bool is_fixed = (len > 64) ? (flags[(size_t)j * stride] != 0) : (((fixed >> j) & 1ull) != 0);
-			if (is_fixed) continue;
-			double v = x[(size_t)j * stride] - shift;
-			if (v < mn) {
-				v = mn;
-				if (len > 64) flags[(size_t)j * stride] = 1; else fixed |= 1ull << j;
-				n--;
-				can_terminate = false;
-			}
-			x[(size_t)j * stride] = v;
-		}
-		if (can_terminate) break;
-	}
-}
-
-/* simplex.c:109-143 on up to 8 values held in registers (static indices; entries past len are ignored): the arithmetic of
- * michelot_strided, operation for operation */
-__device__ __forceinline__ void michelot_small(double (&x)[8], int len, double mn)
-{
-	unsigned fixed = 0u;
-	int n = len;
-	while (n) {
-		double csum = 0.0;
-#pragma unroll
-		for (int j = 0; j < 8; j++)
-			if (j < len) csum += x[j];
-		const double shift = (csum - 1.0) / (double)n;
-		bool can_terminate = true;
-#pragma unroll
-		for (int j = 0; j < 8; j++) {
-			if (j >= len || ((fixed >> j) & 1u)) continue;
-			double v = x[j] - shift;
-			if (v < mn) {
-				v = mn;
-				fixed |= 1u << j;
-				n--;
-				can_terminate = false;
-			}
-			x[j] = v;
-		}
-		if (can_terminate) break;
-	}
-}
 
 /* P[to][l,.][k] = normalise(P[from] * sum_chunks Apart) then project (em_alg.c:706-752); thread = (l,k).  Loci with at most 8
  * alleles (nearly always) are summed, normalised and projected in registers and written once; longer ones go through memory */
@@ -1066,78 +1013,14 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_p(int L, int K, int T,
 	if (do_projection) michelot_strided(Pto + (size_t)c0 * K + k, K, M, lb, flags ? flags + (size_t)c0 * K + k : nullptr);
 }
 
-/* The same with the memory side done by whole blocks.  k_finalize_p's (l, k) threads walk their M elements K doubles apart: every
- * load instruction of a wave touches eight half-used cache lines, and the slab reads ran at 2.9 TB/s (40 us per launch at config
- * 3, the largest of the small kernels of a cycle).  Here a block owns FP_LOCI consecutive loci, i.e. one contiguous run of
- * (c1 - c0) * K elements of every slab: phase 1 adds the slabs element by element, coalesced, into LDS (same sums, same order:
- * ordered_sum over the slabs, times P[from], plus the additive bound); phase 2 is k_finalize_p's arithmetic per (l, k) on the LDS
- * copy; phase 3 stores the run, coalesced.  Same bits as k_finalize_p.  Used while FP_LOCI loci of max_M alleles fit the tile. */
-constexpr int FP_TILE = 1024;	/* doubles of LDS per block: four elements per thread, all of a thread's slab loads in flight at once */
+/* k_finalize_p with the memory side done by whole blocks (mchip_finalize.h: finalize_p_tile_body) */
 __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_p_tile(int L, int K, int T, const int32_t *__restrict__ toff, int loci_per_block,
 		int n_slabs, const double *__restrict__ Apart, const double *Pfrom, double *Pto,
 		int weighted, double add_lb, int do_projection, double lb, const int *stop = nullptr)
 {
 	__shared__ double tile[FP_TILE];
 	if (stop && *stop) return;
-	const int l0 = blockIdx.x * loci_per_block, l1 = min(L, l0 + loci_per_block);
-	const int c0 = toff[l0], c1 = toff[l1];
-	const int nel = (c1 - c0) * K;
-	const size_t e0 = (size_t)c0 * K, slab = (size_t)T * K;
-	if (nel > 0) {	/* a thread's (up to) four elements side by side: their loads of one slab go out together, the sums keep the slab order */
-		double v[FP_TILE / MCHIP_BLOCK];
-#pragma unroll
-		for (int y = 0; y < FP_TILE / MCHIP_BLOCK; y++) v[y] = 0.0;
-		for (int sl = 0; sl < n_slabs; sl++) {
-			double w[FP_TILE / MCHIP_BLOCK];
-#pragma unroll
-			for (int y = 0; y < FP_TILE / MCHIP_BLOCK; y++) {
-				const int x = min((int)threadIdx.x + y * MCHIP_BLOCK, nel - 1);
-				w[y] = Apart[(size_t)sl * slab + e0 + x];
-			}
-#pragma unroll
-			for (int y = 0; y < FP_TILE / MCHIP_BLOCK; y++) v[y] += w[y];
-		}
-#pragma unroll
-		for (int y = 0; y < FP_TILE / MCHIP_BLOCK; y++) {
-			const int x = threadIdx.x + y * MCHIP_BLOCK;
-			if (x < nel) {
-				double t = v[y];
-				if (weighted) t *= Pfrom[e0 + x];
-				tile[x] = t + add_lb;
-			}
-		}
-	}
-	__syncthreads();
-	for (int y = threadIdx.x; y < (l1 - l0) * K; y += MCHIP_BLOCK) {
-		const int k = y % K, l = l0 + y / K;
-		const int m0 = toff[l] - c0, M = toff[l + 1] - toff[l];
-		double *col = tile + (size_t)m0 * K + k;	/* the locus's M values of cluster k, K doubles apart */
-		double temp = 0.0;
-		if (M <= 8) {
-			double v[8];
-#pragma unroll
-			for (int m = 0; m < 8; m++) {
-				v[m] = 0.0;
-				if (m < M) {
-					v[m] = col[(size_t)m * K];
-					temp += v[m];
-				}
-			}
-#pragma unroll
-			for (int m = 0; m < 8; m++)
-				if (m < M) v[m] /= temp;
-			if (do_projection) michelot_small(v, M, lb);
-#pragma unroll
-			for (int m = 0; m < 8; m++)
-				if (m < M) col[(size_t)m * K] = v[m];
-		} else {
-			for (int m = 0; m < M; m++) temp += col[(size_t)m * K];
-			for (int m = 0; m < M; m++) col[(size_t)m * K] /= temp;
-			if (do_projection) michelot_strided(col, K, M, lb, nullptr);	/* (M <= 64 here: the fixed set is a bit mask) */
-		}
-	}
-	__syncthreads();
-	for (int x = threadIdx.x; x < nel; x += MCHIP_BLOCK) Pto[e0 + x] = tile[x];
+	finalize_p_tile_body(blockIdx.x, tile, L, K, T, toff, loci_per_block, n_slabs, Apart, Pfrom, Pto, weighted, add_lb, do_projection, lb);
 }
 
 /* loci per block of k_finalize_p_tile for this data set and K, or 0 where a locus can outgrow the tile (k_finalize_p then) */
@@ -2251,7 +2134,21 @@ static int run_estep(mchip_context *ctx, int from, int to, int do_mstep, const i
 	ctx->s_cache_slot = -1;		/* Spart is consumed below; slot `to` is about to change */
 	const int indiv = ctx->qstride != 0;
 	const int s_slabs = ctx->kt->ind_slabs(a), n_slabs = ctx->kt->col_slabs(a, 0);	/* what the passes above left (cooperating waves: a quarter) */
-	/* k_finalize_q adds the slabs itself, four threads per individual (no slab-sum launch in front of it: at config 2 that launch
+	/* an M step with individual mixing proportions whose P side takes the tiled form: both finalisers in one launch */
+	const int p_loci = finalize_p_loci(ctx->K, ctx->max_M);
+	if (do_mstep && indiv && p_loci && !(n_slabs > 8 && !ctx->knob.no_slab_sum) && !ctx->knob.no_fused_finalize) {
+		mchip_finalize_p_args p;
+		p.L = ctx->L; p.K = ctx->K; p.T = ctx->T; p.loci_per_block = p_loci; p.n_slabs = n_slabs; p.weighted = 1;
+		p.do_projection = ctx->do_projection; p.toff = ctx->d_toff; p.Apart = ctx->d_Apart; p.Pfrom = ctx->d_p[from];
+		p.Pto = ctx->d_p[to]; p.add_lb = 0.0; p.lb = ctx->p_lb;
+		ctx->kt->finalize_qp(ctx->I, s_slabs, ctx->d_Spart, ctx->d_q[from], ctx->qstride, ctx->d_q[to], ctx->d_sik,
+				     ctx->do_projection, ctx->eta_lb, p, stop, ctx->stream);
+		ctx->empty_rows_nan[to] = 1;
+		HIPCHK(hipGetLastError());
+		ctx->have_ll = 1;
+		return MCHIP_OK;
+	}
+	/* k_finalize_q adds the slabs itself, eight threads per individual (no slab-sum launch in front of it: at config 2 that launch
 	 * was 4 of the 137 us of a step, at config 3 two of the cycle's small kernels) */
 	ctx->kt->finalize_q(ctx->I, ctx->K, s_slabs, ctx->d_Spart, ctx->d_q[from], ctx->qstride,
 			    ctx->d_q[to], ctx->d_sik, do_mstep && indiv, 1, ctx->do_projection, ctx->eta_lb, stop, ctx->stream, 0.0);

@@ -147,6 +147,15 @@ struct mchip_pass_args {
 					 * 1: one count per copy, missing copies count for the individual (initialize_parameters_admixture) */
 };
 
+/* what the P-side part of a launch needs (k_finalize_qp takes it by value beside the Q side's arguments; mchip_finalize.h has the code) */
+struct mchip_finalize_p_args {
+	int L, K, T, loci_per_block, n_slabs, weighted, do_projection;
+	const int32_t *toff;
+	const double *Apart, *Pfrom;
+	double *Pto;
+	double add_lb, lb;
+};
+
 /* per-K kernel table (one translation unit per K keeps each hipcc job small and `make -j` parallel) */
 struct mchip_ktable {
 	void (*accum_p)(const mchip_pass_args &a, hipStream_t s);	/* column pass: Apart + logL */
@@ -172,6 +181,9 @@ struct mchip_ktable {
 	int (*col_slabs)(const mchip_pass_args &a, int mix);
 	int (*ind_slabs)(const mchip_pass_args &a);
 	int (*ind_ll_parts)(const mchip_pass_args &a);
+	/* both finalisers of an EM step in one launch (k_finalize_qp): individual mixing proportions, tiled P side */
+	void (*finalize_qp)(int I, int n_slabs_q, const double *Spart, const double *Qfrom, int qstride_from, double *Qto, double *sik,
+			    int do_projection_q, double lb_q, const mchip_finalize_p_args &p, const int *stop, hipStream_t s);
 };
 
 const mchip_ktable *mchip_get_ktable(int K);

@@ -17,6 +17,7 @@
  * (one v_log-free multiply per allele copy, one log per flush), see DESIGN.md.
  */
 #include "mchip_internal.h"
+#include "mchip_finalize.h"
 
 #ifndef MCHIP_K
 #error "compile with -DMCHIP_K=<K>"
@@ -1624,18 +1625,18 @@ __device__ __forceinline__ void michelot_k(double (&x)[K], double mn)
 /* Q[to][i][.] = normalise(q_ik * sum_chunks Spart) then project (em_alg.c:685-701); also stores the
  * expected counts S_ik the writers need (write_file.c:359-381). */
 constexpr int FQ_LANES = 8, FQ_IND = MCHIP_BLOCK / FQ_LANES;	/* threads per individual / individuals per block of k_finalize_q */
-__global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_q(int I, int n_lchunks, const double *__restrict__ Spart,
+constexpr int FQ_XCH = (K <= 16 ? FQ_LANES - 1 : 1) * K * FQ_IND;	/* doubles of LDS a block exchanges its partial sums through */
+__device__ __forceinline__ void finalize_q_body(int block, double *xch_raw, int I, int n_lchunks, const double *__restrict__ Spart,
 		const double *__restrict__ Qfrom, int qstride_from, double *Qto, double *sik,
-		int do_mstep, int weighted, int do_projection, double lb, const int *stop, double add)
+		int do_mstep, int weighted, int do_projection, double lb, double add)
 {
 	/* FQ_IND individuals per block, FQ_LANES threads each: thread g of an individual adds slabs g, g + 8, ... (four loads in
 	 * flight at a time), the partial sums meet in LDS in the order g = 0 .. 7, and thread 0 of the individual carries on.  Every
 	 * slab count is handled here: there is no separate slab-sum launch in front (k_sum_slabs took this scheme's place) */
 	constexpr int TURNS = K <= 16 ? 1 : FQ_LANES - 1;	/* K <= 16: all partial sums at once (28 KB of LDS at most); above: in turns */
-	__shared__ double xch[K <= 16 ? FQ_LANES - 1 : 1][K][FQ_IND];
-	if (stop && *stop) return;		/* (uniform over the grid) */
+	double (*xch)[K][FQ_IND] = reinterpret_cast<double (*)[K][FQ_IND]>(xch_raw);	/* [K <= 16 ? FQ_LANES - 1 : 1][K][FQ_IND] */
 	const int il = threadIdx.x % FQ_IND, g = threadIdx.x / FQ_IND;
-	const int i = blockIdx.x * FQ_IND + il;
+	const int i = block * FQ_IND + il;
 	const bool active = i < I;
 	double s[K];
 #pragma unroll
@@ -1712,6 +1713,30 @@ __global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_q(int I, int n_lchunks
 	if (do_projection) michelot_k(s, lb);
 #pragma unroll
 	for (int k = 0; k < K; k++) Qto[(size_t)i * K + k] = s[k];
+}
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_q(int I, int n_lchunks, const double *__restrict__ Spart,
+		const double *__restrict__ Qfrom, int qstride_from, double *Qto, double *sik,
+		int do_mstep, int weighted, int do_projection, double lb, const int *stop, double add)
+{
+	__shared__ double xch[FQ_XCH];
+	if (stop && *stop) return;		/* (uniform over the grid) */
+	finalize_q_body(blockIdx.x, xch, I, n_lchunks, Spart, Qfrom, qstride_from, Qto, sik, do_mstep, weighted, do_projection, lb, add);
+}
+/* Both finalisers of an EM step in ONE launch: blocks 0 .. q_blocks-1 are k_finalize_q's, the others k_finalize_p_tile's
+ * (mchip_finalize.h).  The two read different sums and write different parameters; a small data set's step is five launches of
+ * a few microseconds around its two passes, and this is one of them less (and the two run beside each other).  Same bodies,
+ * same bits as the two launches. */
+__global__ __launch_bounds__(MCHIP_BLOCK) void k_finalize_qp(int q_blocks, int I, int n_lchunks, const double *__restrict__ Spart,
+		const double *__restrict__ Qfrom, int qstride_from, double *Qto, double *sik,
+		int do_projection_q, double lb_q, mchip_finalize_p_args p, const int *stop)
+{
+	__shared__ double lds[FQ_XCH > FP_TILE ? FQ_XCH : FP_TILE];
+	if (stop && *stop) return;		/* (uniform over the grid) */
+	if ((int)blockIdx.x < q_blocks)		/* (uniform over the block) */
+		finalize_q_body(blockIdx.x, lds, I, n_lchunks, Spart, Qfrom, qstride_from, Qto, sik, 1, 1, do_projection_q, lb_q, 0.0);
+	else
+		finalize_p_tile_body((int)blockIdx.x - q_blocks, lds, p.L, p.K, p.T, p.toff, p.loci_per_block, p.n_slabs, p.Apart, p.Pfrom, p.Pto,
+				     p.weighted, p.add_lb, p.do_projection, p.lb);
 }
 
 /* projection of nrows rows of K (accelerated updates, accel_em.c:510-511; shared eta row) */
@@ -1904,6 +1929,13 @@ void launch_finalize_q(int I, int, int n_lchunks, const double *Spart, const dou
 	hipLaunchKernelGGL(k_finalize_q, dim3((I + FQ_IND - 1) / FQ_IND), dim3(MCHIP_BLOCK), 0, s,
 			   I, n_lchunks, Spart, Qfrom, qstride_from, Qto, sik, do_mstep, weighted, do_projection, lb, stop, add);
 }
+void launch_finalize_qp(int I, int n_lchunks, const double *Spart, const double *Qfrom, int qstride_from, double *Qto, double *sik,
+			int do_projection_q, double lb_q, const mchip_finalize_p_args &p, const int *stop, hipStream_t s)
+{
+	const int q_blocks = (I + FQ_IND - 1) / FQ_IND, p_blocks = (p.L + p.loci_per_block - 1) / p.loci_per_block;
+	hipLaunchKernelGGL(k_finalize_qp, dim3(q_blocks + p_blocks), dim3(MCHIP_BLOCK), 0, s,
+			   q_blocks, I, n_lchunks, Spart, Qfrom, qstride_from, Qto, sik, do_projection_q, lb_q, p, stop);
+}
 void launch_project_q(int nrows, int, double *Q, double lb, const int *stop, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_project_q, dim3((nrows + MCHIP_BLOCK - 1) / MCHIP_BLOCK), dim3(MCHIP_BLOCK), 0, s, nrows, Q, lb, stop);
@@ -1919,7 +1951,7 @@ const mchip_ktable *MCHIP_CAT(mchip_ktable_get_, MCHIP_K)()
 	static mchip_ktable t = {
 		launch_accum_p, launch_loglik, launch_accum_q, launch_part_p, launch_part_q, launch_finalize_q, launch_project_q,
 		launch_mix_gather, launch_mix_finalize, launch_mix_column, dual_available, launch_accum_q_dual,
-		col_slabs, ind_slabs, ind_ll_parts,
+		col_slabs, ind_slabs, ind_ll_parts, launch_finalize_qp,
 	};
 	return &t;
 }
