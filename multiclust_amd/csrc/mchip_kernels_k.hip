@@ -965,10 +965,9 @@ __global__ __launch_bounds__(64 * MCHIP_IND_WAVES_MAX) void k_individual_sparse_
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int W = a.ind_waves;
 	/* which (tile of 64 individuals, slab row) this workgroup is: coop_rows() */
-	const int n_tiles = (a.I + 63) / 64, n_rows = mchip_ind_slabs(a);
+	const int n_tiles = (a.I + 63) / 64;
 	const int slot = a.xcd_rows ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
 	const int bx = slot % n_tiles, by = a.xcd_rows ? (slot / n_tiles) * 8 + (int)(blockIdx.x & 7) : slot / n_tiles;
-	(void)n_rows;
 	const size_t tile_doubles = tile_stride(a.tile_cols);
 	double *mine = lds + (size_t)wv * 2 * SETS * tile_doubles;
 	const int i_raw = bx * 64 + lane;
