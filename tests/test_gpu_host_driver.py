@@ -440,3 +440,29 @@ def test_dual_individual_pass_equals_the_two_passes(K, maxal, missing, scheme, m
     for other in out[1:]:
         assert out[0][:4] == other[:4], (out[0][:4], other[:4])
         assert np.array_equal(out[0][4], other[4]) and np.array_equal(out[0][5], other[5]) and np.array_equal(out[0][6], other[6])
+
+
+@pytest.mark.parametrize("K,ploidy,maxal,missing,scheme", [(2, 2, 4, 0.0, 0), (5, 2, 2, 0.0, 0), (8, 2, 4, 0.03, 3), (7, 4, 4, 0.0, 0),
+                                                            (17, 2, 3, 0.0, 0), (30, 2, 4, 0.0, 1), (8, 1, 6, 0.0, 0)])
+def test_one_launch_finaliser_equals_the_two_launches(K, ploidy, maxal, missing, scheme, monkeypatch):
+    """An M step with individual mixing proportions finalises Q and P in ONE launch (k_finalize_qp: the blocks of k_finalize_q and
+    of k_finalize_p_tile in one grid, mchip_finalize.h).  Same bodies: whole fits with it and with MCHIP_NO_FUSED_FINALIZE=1 (the
+    two launches) end on the same bits -- K on both sides of the 16 at which k_finalize_q's exchange changes form, a K with the
+    lane-split passes, plain EM and batched accelerated cycles, haploid to tetraploid."""
+    from multiclust_amd import host
+    from synth import make_dataset
+    ua, geno = make_dataset(260, 500, K, ploidy=ploidy, max_alleles=maxal, seed=31 + K, missing=missing)
+    out = []
+    for env in ({}, {"MCHIP_NO_FUSED_FINALIZE": "1"}):
+        monkeypatch.delenv("MCHIP_NO_FUSED_FINALIZE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        fit = host.Fit(ua, geno, K, admixture=1, accel_scheme=scheme, verbosity=1, max_iter=20)
+        fit.initialize(99)
+        fit.em()
+        m = fit.mod
+        assert m.fatal == 0
+        out.append((m.n_iter, m.converged, m.iter_stop, m.logL, fit.get_q(m.pindex), fit.get_p(m.pindex), fit.expected_counts()))
+        fit.close()
+    assert out[0][:4] == out[1][:4], (out[0][:4], out[1][:4])
+    assert np.array_equal(out[0][4], out[1][4], equal_nan=True) and np.array_equal(out[0][5], out[1][5]) and np.array_equal(out[0][6], out[1][6])
